@@ -1,0 +1,189 @@
+/*
+ * rsv.h — C-ABI drop-in boundary of the MI355X-native batch verifier for
+ * Poseidon31-channel "Plonk-with-Poseidon" Circle-STARK proofs.
+ *
+ * The reference (Bitcoin-Wildlife-Sanctuary/recursive-stwo) has no FFI of its
+ * own: the verify path is reached through Rust generics.  Every entry point
+ * below names the reference item whose *values* it replaces (paths relative to
+ * the reference root); INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - All field elements are canonical M31 words (0 <= w < 2^31-1) in
+ *     little-endian u32.  QM31 = 4 words (a0,a1,b0,b1) for (a0+a1*i)+(b0+b1*i)*u.
+ *     A hash is 8 words.
+ *   - Return value: RSV_OK (0) on success, negative rsv_status on API misuse
+ *     or device failure.  A proof that does not verify is DATA
+ *     (accept[i]=0, reason[i]=why), never an error and never an abort.
+ *   - The caller owns every buffer.  Functions taking `device` copy host
+ *     buffers to that HIP device and back (stream-ordered, synchronous on
+ *     return).  `_dev` variants take device pointers already resident in HBM
+ *     and enqueue on the context's stream.
+ *   - There is NO CPU fallback in this library: if no HIP device is usable the
+ *     call fails with RSV_E_DEVICE.
+ *   - Thread-safety: distinct rsv_ctx objects may be used concurrently; one
+ *     ctx is single-threaded (mirrors the `!Send` reference types,
+ *     constraint_system/src/lib.rs:33).
+ */
+#ifndef RSV_H_
+#define RSV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSV_M31_P 0x7fffffffu
+#define RSV_ABI_VERSION 1
+
+typedef enum rsv_status {
+    RSV_OK = 0,
+    RSV_E_NULL = -1,     /* required pointer is NULL */
+    RSV_E_SIZE = -2,     /* inconsistent sizes / offsets not monotone / n too large */
+    RSV_E_DEVICE = -3,   /* no such HIP device, or a HIP call failed */
+    RSV_E_CAP = -4,      /* output capacity too small */
+    RSV_E_RANGE = -5     /* input word not a canonical M31 */
+} rsv_status;
+
+/* Why proof i was rejected.  Order = the order in which the reference's
+ * stages would panic (examples/single-proof/src/main.rs:33-82). */
+typedef enum rsv_reason {
+    RSV_R_OK = 0,
+    RSV_R_PARSE = 1,        /* bincode shape / config mismatch (examples/single-proof/src/main.rs:24-31) */
+    RSV_R_POW = 2,          /* components/recursive/fiat_shamir/src/lib.rs:115-117 */
+    RSV_R_LOGUP = 3,        /* components/recursive/fiat_shamir/src/lib.rs:133-141 */
+    RSV_R_COMPOSITION = 4,  /* components/recursive/composition/src/lib.rs:106-120 */
+    RSV_R_DUP_QUERY = 5,    /* components/recursive/answer/src/lib.rs:190-195 */
+    RSV_R_MERKLE_T0 = 6,    /* components/recursive/answer/src/lib.rs:214-258 (tree 0..3) */
+    RSV_R_MERKLE_T1 = 7,
+    RSV_R_MERKLE_T2 = 8,
+    RSV_R_MERKLE_T3 = 9,
+    RSV_R_FRI_FIRST = 10,   /* components/recursive/folding/src/lib.rs:23-54 */
+    RSV_R_FRI_INNER = 11,   /* components/recursive/folding/src/lib.rs:135-192 */
+    RSV_R_FRI_LAST = 12     /* components/recursive/folding/src/lib.rs:194-204 */
+} rsv_reason;
+
+/* stwo PcsConfig{pow_bits, FriConfig::new(log_last_layer_degree_bound,
+ * log_blowup_factor, n_queries)} as written in
+ * examples/multi-proofs/src/main.rs:173-196. */
+typedef struct rsv_pcs_config {
+    uint32_t pow_bits;
+    uint32_t log_blowup_factor;
+    uint32_t log_last_layer_degree_bound;
+    uint32_t n_queries;
+} rsv_pcs_config;
+
+/* One public input `(wire index, QM31 value)` as passed to
+ * FiatShamirResults::compute(.., inputs) (components/recursive/fiat_shamir/src/lib.rs:31-36). */
+typedef struct rsv_public_input {
+    uint32_t idx;
+    uint32_t value[4];
+} rsv_public_input;
+
+/* Opaque per-device context: HIP stream + reusable HBM workspace. */
+typedef struct rsv_ctx rsv_ctx;
+
+int rsv_abi_version(void);
+/* Number of usable HIP devices (0 if none; never fails). */
+int rsv_device_count(void);
+int rsv_ctx_create(int device, rsv_ctx** out);
+void rsv_ctx_destroy(rsv_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int rsv_ctx_synchronize(rsv_ctx* ctx);
+/* The context's hipStream_t (as void*), so a caller can order its own work. */
+void* rsv_ctx_stream(rsv_ctx* ctx);
+
+/* ---- a3: Poseidon2-M31 width-16 permutation -------------------------------
+ * Replaces poseidon2_permute (primitives/poseidon31/src/implementation.rs:108-149).
+ * n states of 16 words, state-major (state i at in16 + 16*i). */
+int rsv_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n, int device);
+int rsv_poseidon2_permute_dev(rsv_ctx* ctx, const uint32_t* d_in16, uint32_t* d_out16, size_t n);
+
+/* ---- a4: Poseidon2HalfVar::permute with swap / rate / capacity ------------
+ * Replaces Poseidon2HalfVar::permute(left,right,_,_,is_swap)
+ * (primitives/poseidon31/src/lib.rs:282-423), values only.
+ * For each i: state = swap[i] ? right_i||left_i : left_i||right_i; permute;
+ * out_rate8 = state[0..8], out_cap8 = state[8..16].  swap, out_rate8 or
+ * out_cap8 may be NULL (no swap / result ignored). */
+int rsv_poseidon2_half_permute(const uint32_t* left8, const uint32_t* right8,
+                               const uint8_t* swap, uint32_t* out_rate8,
+                               uint32_t* out_cap8, size_t n, int device);
+
+/* ---- a5: Poseidon31 Merkle hasher -----------------------------------------
+ * Replaces Poseidon31MerkleHasherVar::{hash_tree, hash_tree_with_column,
+ * hash_m31_columns_get_rate, ...} (primitives/merkle/src/lib.rs:9-181) ==
+ * stwo Poseidon31MerkleHasher::hash_node(children, columns).
+ * n nodes; node i has children left8+8*i / right8+8*i (both NULL => leaves)
+ * and n_cols column words at cols + n_cols*i (n_cols may be 0 iff children given). */
+int rsv_merkle_hash_node(const uint32_t* left8, const uint32_t* right8,
+                         const uint32_t* cols, size_t n_cols, uint32_t* out8,
+                         size_t n, int device);
+
+/* ---- a9: one authentication path per query --------------------------------
+ * Replaces SinglePathMerkleProofVar::verify
+ * (components/recursive/data_structures/src/lib.rs:315-354).
+ * n independent paths of equal `depth`; path i: query position query[i],
+ * siblings sib8 + 8*depth*i (leaf level first), column words laid out per
+ * level: level h (depth..0) has n_cols_at[h] words for every path, packed
+ * level-major from the leaf level down (cols + i*sum(n_cols_at)).
+ * out_root8 receives the recomputed root (8 words per path). */
+int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8,
+                         const uint32_t* cols, const uint32_t* n_cols_at /* depth+1 */,
+                         uint32_t depth, uint32_t* out_root8, size_t n, int device);
+
+/* ---- a6/a7: Fiat-Shamir transcript (parity probe) -------------------------
+ * Replaces FiatShamirResults::compute (components/recursive/fiat_shamir/src/lib.rs:31-176).
+ * out layout (u32 words):
+ *   [0]      reason after transcript stage (RSV_R_OK / PARSE / POW)
+ *   [1]      n_fri_alphas = 1 + n_inner_layers
+ *   [2]      n_queries
+ *   [3]      M = log size of the largest committed column (query bits)
+ *   [4..8)   z          [8..12)  alpha       [12..16) random_coeff
+ *   [16..20) oods_t     [20..24) oods.x      [24..28) oods.y
+ *   [28..32) after_sampled_values_random_coeff
+ *   [32..40) channel digest after the proof-of-work mix
+ *   [40..40+4*n_fri_alphas)  fri alphas
+ *   then n_queries raw query words (before masking to M bits).
+ * Returns RSV_E_CAP if cap (in words) is too small. */
+int rsv_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap, int device);
+
+/* ---- full verify: a1-a13 --------------------------------------------------
+ * Replaces the stage sequence FiatShamirResults::compute →
+ * CompositionCheck::compute → AnswerResults::compute → FoldingResults::compute
+ * (examples/single-proof/src/main.rs:48-82) on a batch of serialized
+ * PlonkWithPoseidonProof<Poseidon31MerkleHasher> (bincode).
+ *   blob     concatenated proof bytes; proof i = blob[offsets[i] .. offsets[i+1])
+ *   cfg      NULL = trust the config serialized in each proof; else a proof
+ *            whose embedded config differs is rejected with RSV_R_PARSE
+ *   pi,n_pi  public inputs shared by the whole batch
+ *   accept   n bytes, 1 = verified        reason  n bytes of rsv_reason (may be NULL)
+ */
+int rsv_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
+                     const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
+                     uint8_t* accept, uint8_t* reason, int device);
+
+/* Same, inputs and outputs resident in HBM (d_ = device pointers); enqueued on
+ * ctx's stream, returns without synchronising.  d_offsets must be 8-byte
+ * aligned, d_blob 4-byte aligned and every offset a multiple of 4 (bincode
+ * proofs of this type always have 4-byte-multiple lengths). */
+int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets,
+                         size_t n, const rsv_pcs_config* cfg, const rsv_public_input* pi,
+                         size_t n_pi, uint8_t* d_accept, uint8_t* d_reason);
+
+/* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
+ * words (device) and return the popcount through *d_count (device u64, may be NULL).
+ * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */
+int rsv_accept_bitmap_dev(rsv_ctx* ctx, const uint8_t* d_accept, size_t n,
+                          uint32_t* d_bitmap, uint64_t* d_count);
+
+/* Per-stage kernel time of the last rsv_verify_batch_dev on this ctx, measured
+ * with HIP events on the ctx stream (ms).  names[i] are static strings.
+ * Returns the number of stages written (<= cap).  Synchronises the stream. */
+int rsv_last_stage_times(rsv_ctx* ctx, const char** names, float* ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSV_H_ */

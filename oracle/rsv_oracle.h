@@ -1,0 +1,60 @@
+/*
+ * rsv_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the recursive-stwo verify path
+ * (see rsv_oracle.c for the per-function reference citations).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (recursive-stwo_amd/csrc) never links or calls it.
+ *
+ * Parity status: PINNED by (a) the reference's literal Poseidon2 known-answer
+ * test (primitives/poseidon31/src/implementation.rs:157-172) and (b) the
+ * reference's 15 Poseidon-channel proof fixtures, each of which must ACCEPT
+ * under the config written in the reference source, plus the SHA-256-channel
+ * fixture which must REJECT.  The Rust reference itself cannot
+ * be built in this image (no cargo/rustc; stwo dependency un-vendored).
+ */
+#ifndef RSV_ORACLE_H_
+#define RSV_ORACLE_H_
+#include "../include/rsv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same semantics as the rsv_* functions of include/rsv.h, computed on the CPU. */
+int rsvo_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n);
+int rsvo_poseidon2_half_permute(const uint32_t* left8, const uint32_t* right8,
+                                const uint8_t* swap, uint32_t* out_rate8,
+                                uint32_t* out_cap8, size_t n);
+int rsvo_merkle_hash_node(const uint32_t* left8, const uint32_t* right8,
+                          const uint32_t* cols, size_t n_cols, uint32_t* out8, size_t n);
+int rsvo_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint32_t* cols,
+                          const uint32_t* n_cols_at, uint32_t depth, uint32_t* out_root8,
+                          size_t n);
+int rsvo_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap);
+int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
+                      const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
+                      uint8_t* accept, uint8_t* reason);
+
+/* Extra probes used by the tests. */
+/* Number of Poseidon2 permutations executed by the calling thread since the
+ * last reset (transcript + batched Merkle), SURVEY App. C. */
+uint64_t rsvo_perm_count(void);
+void rsvo_perm_count_reset(void);
+/* Field probes: out = a*b, out = a^-1 in QM31 (4 words each). */
+void rsvo_qm31_mul(const uint32_t* a, const uint32_t* b, uint32_t* out);
+void rsvo_qm31_inv(const uint32_t* a, uint32_t* out);
+/* CanonicCoset(log).circle_domain().at(bit_reverse(q, log)) -> (x, y). */
+void rsvo_domain_point(uint32_t log_size, uint32_t q, uint32_t* xy);
+/* Per-query intermediate values of one proof (for kernel-level parity tests):
+ * out receives, for every query j in transcript order, the DEEP-quotient
+ * answers for the distinct column log sizes in descending order
+ * (n_sizes*4 words) followed by the value entering the last-layer check (4 words).
+ * Returns the number of words written or a negative rsv_status. */
+int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi,
+                      uint32_t* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
