@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — recursive proofs verified / s on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the verify pipeline over one synthetic batch that is already resident in HBM:
+BASELINE configs[2], 65 536 proofs built round-robin from the reference's four standard-config fixtures
+(recursive_proof_16_15, level3-1, level6-1, level7-1) with the seeded tamper rule of SURVEY §8d
+(proof i with i % 17 == 5 gets one flipped bit).  With --gpus N every rank verifies its own
+65 536-proof shard of an N x 65 536 batch (weak scaling) and the accept bitmaps are exchanged with one
+all_gather per step (RCCL).  Rank 0 prints ONE JSON line.
+
+Launch: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FIXTURES = ["recursive_proof_16_15.bin", "level3-1.bin", "level6-1.bin", "level7-1.bin"]
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def splitmix64(seed, i):
+    mask = (1 << 64) - 1
+    z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & mask
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+    return z ^ (z >> 31)
+
+
+def read_fixture(name):
+    with open(os.path.join(ROOT, "tests", "golden", "proofs", name), "rb") as f:
+        return f.read()
+
+
+def build_batch_on_device(torch, dev, n_proofs, first_index):
+    """Returns (d_blob uint8, d_offsets int64[n+1], lengths, tamper byte offsets) for global proof
+    indices [first_index, first_index + n_proofs)."""
+    proofs = [read_fixture(f) for f in FIXTURES]
+    lens = np.array([len(p) for p in proofs], dtype=np.int64)
+    idx = (np.arange(n_proofs, dtype=np.int64) + first_index) % len(proofs)
+    plen = lens[idx]
+    offsets = np.zeros(n_proofs + 1, dtype=np.int64)
+    np.cumsum(plen, out=offsets[1:])
+    total = int(offsets[-1])
+    # one period (4 proofs, aligned to the round-robin phase) tiled across the batch, built in HBM
+    phase = int(first_index % len(proofs))
+    order = [(phase + k) % len(proofs) for k in range(len(proofs))]
+    period = np.frombuffer(b"".join(proofs[k] for k in order), dtype=np.uint8)
+    d_period = torch.from_numpy(period.copy()).to(dev)
+    reps = (n_proofs + len(proofs) - 1) // len(proofs)
+    d_blob = d_period.repeat(reps)[:total].contiguous()
+    # seeded tampering
+    tam = [i for i in range(n_proofs) if (first_index + i) % 17 == 5]
+    pos = np.array([offsets[i] + 60 + splitmix64(0xC0FFEE, first_index + i) % (int(plen[i]) - 68) for i in tam],
+                   dtype=np.int64)
+    if len(pos):
+        d_pos = torch.from_numpy(pos).to(dev)
+        d_blob[d_pos] = d_blob[d_pos] ^ 1
+    d_offsets = torch.from_numpy(offsets).to(dev)
+    return d_blob, d_offsets, plen, np.array(tam, dtype=np.int64)
+
+
+def cpu_baseline(blob_host, offsets, n_sample):
+    """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores."""
+    from tests import oracle_binding as ob
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    n_sample = min(n_sample, len(offsets) - 1)
+    bounds = np.linspace(0, n_sample, threads + 1).astype(int)
+    pi = ob.make_inputs(ob.STANDARD_INPUTS)
+
+    def work(t):
+        lo, hi = bounds[t], bounds[t + 1]
+        if hi <= lo:
+            return 0
+        offs = np.ascontiguousarray(offsets[lo:hi + 1], dtype=np.uint64)
+        acc = np.zeros(hi - lo, np.uint8)
+        rc = ob.lib.rsvo_verify_batch(blob_host.ctypes.data_as(ob._u8p), offs.ctypes.data_as(ob._u64p), hi - lo, None,
+                                      pi, 3, acc.ctypes.data_as(ob._u8p), None)
+        assert rc == 0
+        return int(acc.sum())
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        accepted = sum(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proofs", type=int, default=65536, help="proofs per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="oracle sample size (0 = skip, -1 = auto)")
+    ap.add_argument("--perm-log2", type=int, default=24, help="Poseidon2 microbench size (log2 states, 0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rsvload
+    rsv = rsvload.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
+    if not torch.cuda.is_available() or rsv.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.proofs
+    first = rank * n
+    d_blob, d_offsets, plen, tam = build_batch_on_device(torch, dev, n, first)
+    total_bytes = int(plen.sum())
+    d_accept = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+    n_words = (n + 31) // 32
+    d_bitmap = torch.zeros(n_words, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_all = torch.zeros(world * n_words, dtype=torch.int32, device=dev) if world > 1 else None
+    ctx = rsv.Context(local_rank)
+
+    def step():
+        ctx.verify_batch(d_blob, d_offsets, n, d_accept, d_reason)
+        ctx.accept_bitmap(d_accept, n, d_bitmap, d_count)
+        if world > 1:
+            ctx.synchronize()  # bitmap produced on the verifier's stream, exchanged on torch's
+            dist.all_gather_into_tensor(d_all, d_bitmap)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage_sum = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event stage times of this step (reads events already recorded on the stream)
+        if rank == 0:
+            for k, v in ctx.last_stage_times().items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # correctness of what was just timed: every untampered proof accepted, every tampered one rejected
+    acc = d_accept.cpu().numpy()
+    want = np.ones(n, np.uint8)
+    want[tam] = 0
+    if not np.array_equal(acc, want):
+        raise SystemExit(f"rank {rank}: verdict mismatch: {int((acc != want).sum())} proofs differ from the expected accept map")
+    if int(d_count.item()) != int(want.sum()):
+        raise SystemExit("accept popcount mismatch")
+    if world > 1:
+        allbits = np.unpackbits(d_all.cpu().numpy().view(np.uint8), bitorder="little").reshape(world, -1)[:, :n]
+        if int(allbits.sum()) != world * int(want.sum()) - 0 and rank == 0:
+            # tamper sets differ per rank (global index rule); recompute exactly
+            exp = sum(int(((np.arange(n) + r * n) % 17 != 5).sum()) for r in range(world))
+            if int(allbits.sum()) != exp:
+                raise SystemExit("gathered bitmap popcount mismatch")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n * args.steps / dt
+    stage_avg = {k: v / args.steps for k, v in stage_sum.items()}
+    dom = max((k for k in stage_avg if k.endswith("merkle")), key=lambda k: stage_avg[k])
+    dom_ms = stage_avg[dom]
+    algo_bytes = total_bytes + n  # proof bytes read once + 1 accept byte per proof
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    kernel_ms = sum(stage_avg.values())
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms,
+                "pipeline_ms": kernel_ms, "pipeline_GBps": algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0,
+                "stage_ms": stage_avg,
+                "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY §8d); see valu"}
+
+    # Poseidon2 microbench (second metric of BASELINE.json): 2^k states resident in HBM, 128 B per permutation
+    valu = None
+    if args.perm_log2 > 0:
+        m = 1 << args.perm_log2
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1)
+        d_in = torch.randint(0, 0x7FFFFFFF, (m, 16), dtype=torch.int32, device=dev, generator=gen)
+        d_out = torch.empty_like(d_in)
+        ctx.poseidon2_permute(d_in, d_out)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.poseidon2_permute(d_in, d_out)
+        ctx.synchronize()
+        pdt = (time.perf_counter() - t1) / reps
+        perms_per_s = m / pdt
+        valu = {"poseidon2_perms_per_s": perms_per_s, "perm_GBps": m * 128 / pdt / 1e9,
+                "perm_hbm_frac": m * 128 / pdt / 1e9 / HBM_PEAK_GBPS, "states": m}
+        del d_in, d_out
+
+    cpu = None
+    sample = args.cpu_sample
+    if sample != 0:
+        threads = max(1, min(os.cpu_count() or 1, 16))
+        if sample < 0:
+            sample = 640 * threads  # ~5 s per thread at ~8 ms per proof
+        n_s = min(sample, n)
+        end = int(d_offsets[n_s].item())
+        blob_host = d_blob[:end].cpu().numpy()
+        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s)
+
+    line = {
+        "metric": "recursive proofs verified/sec", "value": value, "unit": "proofs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31 modular integers)", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {n} proofs/GPU round-robin over {FIXTURES}, i%17==5 tampered "
+                               f"(SURVEY §8d), full verify; bit-exact accept map checked",
+                   "proofs_per_gpu": n, "bytes_per_gpu": total_bytes, "parallelism": f"shard{world}"},
+        "roofline": roofline, "cpu_baseline": cpu, "valu": valu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

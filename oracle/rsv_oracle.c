@@ -962,8 +962,6 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
     quotient_group* groups = calloc(3, sizeof *groups);
 #define FAIL(r) do { reason = (r); goto done; } while (0)
     if (!parse_proof(bytes, len, cfg, v)) FAIL(RSV_R_PARSE);
-    for (size_t i = 0; i < n_pi; i++)
-        for (int k = 0; k < 4; k++) if (pi[i].value[k] >= P) FAIL(RSV_R_PARSE);
     run_transcript(v, t);
     if (!t->pow_ok) FAIL(RSV_R_POW);
     if (!check_logup(v, t, pi, n_pi)) FAIL(RSV_R_LOGUP);
@@ -1138,6 +1136,7 @@ int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, co
     if (n && (!blob || !offsets || !accept)) return RSV_E_NULL;
     if (n_pi && !pi) return RSV_E_NULL;
     for (size_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return RSV_E_SIZE;
+    for (size_t i = 0; i < n_pi; i++) if (!canonical(pi[i].value, 4)) return RSV_E_RANGE;
     query_probe* scratch = malloc(sizeof *scratch);
     for (size_t i = 0; i < n; i++) {
         uint8_t r = verify_one(blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), cfg, pi, n_pi, scratch);

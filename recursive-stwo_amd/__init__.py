@@ -1,0 +1,279 @@
+"""recursive-stwo_amd — host-side binding of the MI355X-native batch verifier.
+
+This package is plumbing only: it loads ``csrc/librsv_hip.so`` (the C-ABI of
+``include/rsv.h``) with ctypes and exposes the same entry points to Python,
+either on host ``bytes``/numpy arrays (copied to the device by the library) or
+on torch tensors that already live in HBM (``Context``).  There is no CPU
+implementation here: if the library is missing, or no HIP device is usable,
+every call raises.
+
+Reference items mirrored (values only; see include/rsv.h for file:line):
+  poseidon2_permute        primitives/poseidon31/src/implementation.rs:108-149
+  half_permute             Poseidon2HalfVar::permute, primitives/poseidon31/src/lib.rs:282-423
+  hash_node                Poseidon31MerkleHasherVar, primitives/merkle/src/lib.rs:9-181
+  merkle_path_root         SinglePathMerkleProofVar::verify, components/recursive/data_structures/src/lib.rs:315-354
+  transcript               FiatShamirResults::compute, components/recursive/fiat_shamir/src/lib.rs:31-176
+  verify_batch             FiatShamirResults/CompositionCheck/AnswerResults/FoldingResults::compute
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+P = 0x7FFFFFFF
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librsv_hip.so")
+
+REASONS = ["ok", "parse", "pow", "logup", "composition", "dup_query", "merkle_t0", "merkle_t1",
+           "merkle_t2", "merkle_t3", "fri_first", "fri_inner", "fri_last"]
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class RsvError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        names = {-1: "RSV_E_NULL", -2: "RSV_E_SIZE", -3: "RSV_E_DEVICE", -4: "RSV_E_CAP", -5: "RSV_E_RANGE"}
+        super().__init__(f"{what}: {names.get(code, code)}")
+        self.code = code
+
+
+class PcsConfig(ctypes.Structure):
+    """stwo PcsConfig{pow_bits, FriConfig::new(log_last_layer_degree_bound, log_blowup_factor, n_queries)}."""
+    _fields_ = [("pow_bits", ctypes.c_uint32), ("log_blowup_factor", ctypes.c_uint32),
+                ("log_last_layer_degree_bound", ctypes.c_uint32), ("n_queries", ctypes.c_uint32)]
+
+
+class PublicInput(ctypes.Structure):
+    _fields_ = [("idx", ctypes.c_uint32), ("value", ctypes.c_uint32 * 4)]
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    sz = ctypes.c_size_t
+    vp = ctypes.c_void_p
+    sig = {
+        "rsv_abi_version": (ctypes.c_int, []),
+        "rsv_device_count": (ctypes.c_int, []),
+        "rsv_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
+        "rsv_ctx_destroy": (None, [vp]),
+        "rsv_ctx_synchronize": (ctypes.c_int, [vp]),
+        "rsv_ctx_stream": (vp, [vp]),
+        "rsv_poseidon2_permute": (ctypes.c_int, [_u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_poseidon2_permute_dev": (ctypes.c_int, [vp, vp, vp, sz]),
+        "rsv_poseidon2_half_permute": (ctypes.c_int, [_u32p, _u32p, _u8p, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_merkle_hash_node": (ctypes.c_int, [_u32p, _u32p, _u32p, sz, _u32p, sz, ctypes.c_int]),
+        "rsv_merkle_path_root": (ctypes.c_int, [_u32p, _u32p, _u32p, _u32p, ctypes.c_uint32, _u32p, sz, ctypes.c_int]),
+        "rsv_transcript": (ctypes.c_int, [_u8p, sz, _u32p, sz, ctypes.c_int]),
+        "rsv_verify_batch": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput),
+                                            sz, _u8p, _u8p, ctypes.c_int]),
+        "rsv_verify_batch_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PcsConfig),
+                                                ctypes.POINTER(PublicInput), sz, vp, vp]),
+        "rsv_accept_bitmap_dev": (ctypes.c_int, [vp, vp, sz, vp, vp]),
+        "rsv_last_stage_times": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                                ctypes.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what rsv.h declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_destroy", "rsv_ctx_synchronize",
+           "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
+           "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
+           "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times"]
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RsvError(rc, what)
+
+
+def _u32(a, shape=None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.uint32)
+    if shape is not None:
+        arr = arr.reshape(shape)
+    return arr
+
+
+def device_count() -> int:
+    return lib.rsv_device_count()
+
+
+def make_inputs(inputs: Iterable) -> "ctypes.Array[PublicInput]":
+    """[(idx, (a0, a1, b0, b1)), ...] -> PublicInput array (e.g. (1, 1), (2, i), (3, u))."""
+    items = list(inputs)
+    arr = (PublicInput * max(len(items), 1))()
+    for k, (idx, val) in enumerate(items):
+        arr[k].idx = idx
+        for t in range(4):
+            arr[k].value[t] = int(val[t])
+    return arr
+
+
+#: public inputs used by examples/multi-proofs/src/main.rs:49-57
+STANDARD_INPUTS = [(1, (1, 0, 0, 0)), (2, (0, 1, 0, 0)), (3, (0, 0, 1, 0))]
+
+
+def poseidon2_permute(states, device: int = 0) -> np.ndarray:
+    s = _u32(states).reshape(-1, 16)
+    out = np.empty_like(s)
+    _check(lib.rsv_poseidon2_permute(s.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), s.shape[0], device),
+           "rsv_poseidon2_permute")
+    return out
+
+
+def half_permute(left, right, swap=None, device: int = 0):
+    """Poseidon2HalfVar::permute: returns (rate, capacity), each (n, 8)."""
+    l = _u32(left).reshape(-1, 8)
+    r = _u32(right).reshape(-1, 8)
+    n = l.shape[0]
+    sw = None if swap is None else np.ascontiguousarray(swap, dtype=np.uint8)
+    rate = np.empty((n, 8), np.uint32)
+    cap = np.empty((n, 8), np.uint32)
+    _check(lib.rsv_poseidon2_half_permute(l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p),
+                                          None if sw is None else sw.ctypes.data_as(_u8p),
+                                          rate.ctypes.data_as(_u32p), cap.ctypes.data_as(_u32p), n, device),
+           "rsv_poseidon2_half_permute")
+    return rate, cap
+
+
+def hash_node(children, cols, device: int = 0) -> np.ndarray:
+    """Poseidon31MerkleHasher::hash_node for n nodes.  children = None or (left (n,8), right (n,8));
+    cols = (n, n_cols) array (n_cols may be 0 when children are given)."""
+    c = _u32(cols)
+    if c.ndim == 1:
+        c = c.reshape(1, -1)
+    n, n_cols = c.shape
+    out = np.empty((n, 8), np.uint32)
+    if children is None:
+        lp = rp = None
+    else:
+        l = _u32(children[0]).reshape(n, 8)
+        r = _u32(children[1]).reshape(n, 8)
+        lp, rp = l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p)
+    _check(lib.rsv_merkle_hash_node(lp, rp, c.ctypes.data_as(_u32p) if n_cols else None, n_cols,
+                                    out.ctypes.data_as(_u32p), n, device), "rsv_merkle_hash_node")
+    return out
+
+
+def merkle_path_root(query, siblings, cols, n_cols_at: Sequence[int], device: int = 0) -> np.ndarray:
+    q = _u32(query).reshape(-1)
+    n = q.shape[0]
+    depth = len(n_cols_at) - 1
+    sib = _u32(siblings).reshape(n, depth, 8) if depth else np.zeros((n, 0, 8), np.uint32)
+    nca = _u32(n_cols_at)
+    c = _u32(cols).reshape(n, int(nca.sum()))
+    out = np.empty((n, 8), np.uint32)
+    _check(lib.rsv_merkle_path_root(q.ctypes.data_as(_u32p), sib.ctypes.data_as(_u32p), c.ctypes.data_as(_u32p),
+                                    nca.ctypes.data_as(_u32p), depth, out.ctypes.data_as(_u32p), n, device),
+           "rsv_merkle_path_root")
+    return out
+
+
+def _parse_transcript(out: np.ndarray) -> dict:
+    if out[0] == 1:
+        return {"reason": "parse"}
+    na, nq = int(out[1]), int(out[2])
+    q = lambda o: tuple(int(x) for x in out[o:o + 4])
+    return {
+        "reason": REASONS[int(out[0])], "n_queries": nq, "log_size": int(out[3]),
+        "z": q(4), "alpha": q(8), "random_coeff": q(12), "oods_t": q(16), "oods_x": q(20), "oods_y": q(24),
+        "after_sampled_values_random_coeff": q(28), "pow_digest": [int(x) for x in out[32:40]],
+        "fri_alphas": [q(40 + 4 * i) for i in range(na)],
+        "raw_queries": [int(x) for x in out[40 + 4 * na:40 + 4 * na + nq]],
+    }
+
+
+def transcript(proof: bytes, device: int = 0) -> dict:
+    b = np.frombuffer(proof, dtype=np.uint8)
+    out = np.zeros(1024, np.uint32)
+    _check(lib.rsv_transcript(b.ctypes.data_as(_u8p), len(proof), out.ctypes.data_as(_u32p), out.size, device),
+           "rsv_transcript")
+    return _parse_transcript(out)
+
+
+def pack(proofs: Sequence[bytes]):
+    """Concatenate proofs into (blob uint8[total], offsets uint64[n+1])."""
+    offsets = np.zeros(len(proofs) + 1, np.uint64)
+    if proofs:
+        offsets[1:] = np.cumsum([len(p) for p in proofs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(proofs), dtype=np.uint8) if proofs else np.zeros(0, np.uint8)
+    return blob, offsets
+
+
+def verify_batch(proofs: Sequence[bytes], inputs=STANDARD_INPUTS, cfg: Optional[PcsConfig] = None, device: int = 0):
+    """Verify a batch of serialized proofs on the GPU.  Returns (accept uint8[n], reason uint8[n])."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    _check(lib.rsv_verify_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n,
+                                ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+                                accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_verify_batch")
+    return accept, reason
+
+
+class Context:
+    """One HIP stream + reusable HBM workspace on one device (rsv_ctx).  Operates on torch tensors that
+    already live on that device; nothing is copied through the host."""
+
+    def __init__(self, device: int = 0):
+        h = ctypes.c_void_p()
+        _check(lib.rsv_ctx_create(device, ctypes.byref(h)), "rsv_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.rsv_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib.rsv_ctx_synchronize(self._h), "rsv_ctx_synchronize")
+
+    @property
+    def stream(self) -> int:
+        return lib.rsv_ctx_stream(self._h) or 0
+
+    def poseidon2_permute(self, d_in, d_out):
+        n = d_in.numel() // 16
+        _check(lib.rsv_poseidon2_permute_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), n), "rsv_poseidon2_permute_dev")
+
+    def verify_batch(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS,
+                     cfg: Optional[PcsConfig] = None):
+        pi = make_inputs(inputs)
+        _check(lib.rsv_verify_batch_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n,
+                                        ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+                                        d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
+               "rsv_verify_batch_dev")
+
+    def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):
+        _check(lib.rsv_accept_bitmap_dev(self._h, d_accept.data_ptr(), n, d_bitmap.data_ptr(),
+                                         d_count.data_ptr() if d_count is not None else None), "rsv_accept_bitmap_dev")
+
+    def last_stage_times(self) -> dict:
+        names = (ctypes.c_char_p * 8)()
+        ms = (ctypes.c_float * 8)()
+        k = lib.rsv_last_stage_times(self._h, names, ms, 8)
+        if k < 0:
+            raise RsvError(k, "rsv_last_stage_times")
+        return {names[i].decode(): float(ms[i]) for i in range(k)}

@@ -1,0 +1,120 @@
+// layout.hpp — HBM data layout shared by the verify kernels and the host launcher.
+//
+// A batch is the caller's blob (proof i = blob[offsets[i], offsets[i+1])) plus a
+// per-proof workspace record written by the early stages and read by the
+// later ones.  All "offsets" inside the records are in 32-bit WORDS relative to
+// the start of the proof (every field of the bincode encoding is 4-byte
+// aligned).
+#pragma once
+#include <stdint.h>
+
+namespace rsv {
+
+constexpr int MAXQ = 128;      // max FRI queries per proof (fixtures: 8..80)
+constexpr int MAX_INNER = 28;  // max FRI inner layers (M <= 30)
+constexpr int MAX_LOG = 30;    // max column log size M
+constexpr int N_SAMPLES = 142; // 50+60+16+8 columns, 8 of them with two mask points
+constexpr int N_APOW = 136;    // alpha powers kept for the quotient numerators
+
+// Column counts per commitment tree: plonk | poseidon component.
+__host__ __device__ constexpr uint32_t plonk_cols(int t) { return t == 0 ? 10u : t == 1 ? 12u : t == 2 ? 8u : 0u; }
+__host__ __device__ constexpr uint32_t poseidon_cols(int t) { return t == 0 ? 40u : t == 1 ? 48u : t == 2 ? 8u : 0u; }
+__host__ __device__ constexpr uint32_t tree_cols(int t) { return t == 3 ? 8u : plonk_cols(t) + poseidon_cols(t); }
+// Mask sizes: one sample per column except interaction columns 4-7 and 12-15 ([-1, 0]).
+__host__ __device__ constexpr uint32_t n_samples_of(int t, int c) { return (t == 2 && (c & 4)) ? 2u : 1u; }
+
+// Fixed word offsets of the constant-shape prefix of a proof.
+constexpr uint32_t W_LP = 0, W_LQ = 1, W_PLONK_SUM = 2, W_POSEIDON_SUM = 6, W_POW_BITS = 10, W_BLOWUP = 11,
+                   W_LOG_LAST = 12, W_NQ = 13, W_NCOMMIT = 15, W_COMMIT0 = 17, W_NTREES = 49;
+
+struct SampleTable {
+    uint16_t off[N_SAMPLES];  // word offset of each sampled value (tree-major, column-major, sample-minor)
+    uint16_t col_prefix[134]; // word offset of each column's u64 sample-count prefix
+    uint16_t tree_prefix[4];  // word offset of each tree's u64 column-count prefix
+    uint16_t end;             // first word after sampled_values (= decommitments prefix)
+};
+__host__ __device__ constexpr SampleTable make_sample_table() {
+    SampleTable t{};
+    uint32_t pos = W_NTREES + 2, k = 0, c_all = 0;
+    for (int tr = 0; tr < 4; tr++) {
+        t.tree_prefix[tr] = (uint16_t)pos;
+        pos += 2;
+        for (uint32_t c = 0; c < tree_cols(tr); c++) {
+            t.col_prefix[c_all++] = (uint16_t)pos;
+            pos += 2;
+            for (uint32_t s = 0; s < n_samples_of(tr, (int)c); s++) {
+                t.off[k++] = (uint16_t)pos;
+                pos += 4;
+            }
+        }
+    }
+    t.end = (uint16_t)pos;
+    return t;
+}
+// index of the first sample of each tree inside the flattened sample list
+constexpr int S_T0 = 0, S_T1 = 50, S_T2 = 110, S_T3 = 134;
+
+struct FriLayerRef {
+    uint32_t wit_off, wit_n;    // fri_witness: wit_n QM31 values
+    uint32_t hash_off, hash_n;  // decommitment.hash_witness: hash_n hashes of 8 words
+    uint32_t commit_off;        // layer commitment (8 words)
+};
+
+// Written by k_parse.
+struct ProofMeta {
+    uint32_t reason;  // RSV_R_OK or RSV_R_PARSE
+    uint32_t n_words;
+    uint32_t lp, lq, pow_bits, blowup, log_last, nq, n_inner, A, B, M;
+    uint32_t hw_off[4], hw_n[4];  // trace-tree hash witnesses
+    uint32_t qv_off[4], qv_n[4];  // trace-tree queried values
+    uint32_t nonce_off;
+    FriLayerRef first;
+    FriLayerRef inner[MAX_INNER];
+    uint32_t last_off, last_n;
+};
+
+// Failure flags accumulated by the stages: bit r is set when stage rsv_reason r failed.
+// k_finalize reports the lowest set bit (= the order in which the reference's
+// stages would have panicked).
+
+struct QBatch {
+    uint32_t sa[4], sb[4];            // sum of line coefficients a_k, b_k over the batch (QM31)
+    uint32_t prx[2], pix[2], pry[2], piy[2];  // sample point: x = prx + pix*u, y = pry + piy*u (CM31 each)
+};
+
+// Written by k_transcript / k_plan, read by the per-query kernels.
+struct ProofCtx {
+    uint32_t flags;
+    uint32_t n_sizes;
+    uint32_t sizes[3];       // distinct column log sizes, descending (M first)
+    uint32_t fw_base[3];     // first-layer fri_witness base index per size
+    uint32_t z[4], alpha[4], rc[4], oods_t[4], oods_x[4], oods_y[4], after[4];
+    uint32_t pow_digest[8];
+    uint32_t fri_alpha[MAX_INNER + 1][4];
+    uint32_t raw_q[MAXQ];    // raw query words in transcript order
+    uint32_t q[MAXQ];        // query positions at log M, ascending
+    QBatch batch[3][2];      // per size group: batch 0 = OODS point, batch 1 = OODS - trace step
+    uint32_t n_batches[3];
+    uint32_t apow[N_APOW][4];  // -2u * after^k
+};
+
+// Per-proof decommitment plan (k_plan), indexed by tree level l = 0..M and lane j
+// (lane j owns the j-th smallest query):
+//   ent[l*G + j]  = RB | LB<<8 | SIB<<16
+//       RB  = number of distinct nodes at level l to the left of lane j's node
+//       LB  = number of distinct parents (level l-1) to the left of lane j's
+//             whose other child is not on any query path (=> hash witness)
+//       SIB = lane that owns the sibling node at level l, 0xFF if it comes from the witness
+//   lvl[l]        = ND | TL<<8 | S<<16
+//       ND = distinct nodes at level l, TL = parents at level l-1 lacking a child,
+//       S  = sum of TL over levels >= l
+struct PlanHdr {
+    uint32_t lvl[MAX_LOG + 2];
+    // FRI first-layer tree (column data at levels sizes[0..n_sizes)):
+    uint16_t wf[MAX_LOG + 2];  // hash-witness base index of the step from child level l to l-1
+    uint16_t wf_total, pad;
+};
+// fl[(d*G + j)] for the (up to two) non-leaf data levels d of the first-layer tree:
+//   w_self | w_sib << 16   (0xFFFF = none / sibling owned by lane SIB)
+
+}  // namespace rsv

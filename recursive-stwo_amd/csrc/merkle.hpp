@@ -1,0 +1,89 @@
+// merkle.hpp — Poseidon31 Merkle hasher and Fiat-Shamir channel, device side.
+//
+// Values side of Poseidon31MerkleHasherVar (primitives/merkle/src/lib.rs:9-181),
+// i.e. stwo's Poseidon31MerkleHasher::hash_node(children, columns), and of
+// ChannelVar (primitives/channel/src/lib.rs:24-58).  One lane owns one node /
+// one channel; every function is a short sequence of calls to the single
+// out-of-line poseidon2() instance.
+#pragma once
+#include "poseidon2.hpp"
+
+namespace rsv {
+
+// hash_m31_columns_get_capacity (primitives/merkle/src/lib.rs:141-181):
+// d = 0; for each zero-padded chunk of 8 words: d = perm(chunk || d)[8..16].
+// `cols` may be any address space; words are read with plain 4-byte loads.
+__device__ inline Hash8 sponge_capacity(const uint32_t* cols, uint32_t n) {
+    Hash8 d = zero8();
+    for (uint32_t off = 0; off < n; off += 8) {
+        Hash8 chunk;
+#pragma unroll
+        for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
+        d = perm_cap(chunk, d);
+    }
+    return d;
+}
+// The 4-word (one QM31) column of the FRI trees: hash_qm31_columns_get_capacity of
+// [v, 0] (components/recursive/data_structures/src/lib.rs:408-419).
+__device__ inline Hash8 sponge_capacity4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    Hash8 chunk = zero8();
+    chunk.w[0] = v0; chunk.w[1] = v1; chunk.w[2] = v2; chunk.w[3] = v3;
+    return perm_cap(chunk, zero8());
+}
+// leaf: hash_m31_columns_get_rate (primitives/merkle/src/lib.rs:50-91)
+__device__ inline Hash8 leaf_from_capacity(const Hash8& d) { return perm_rate(zero8(), d); }
+// hash_tree (primitives/merkle/src/lib.rs:9-11)
+__device__ inline Hash8 hash_tree(const Hash8& l, const Hash8& r) { return perm_rate(l, r); }
+// combine_hash_tree_with_column (primitives/merkle/src/lib.rs:43-48)
+__device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate(tree, col_cap); }
+
+// stwo Poseidon31MerkleHasher::hash_node
+__device__ inline Hash8 hash_node(const Hash8* l, const Hash8* r, const uint32_t* cols, uint32_t n_cols) {
+    if (!l) return leaf_from_capacity(sponge_capacity(cols, n_cols));
+    Hash8 h = hash_tree(*l, *r);
+    if (n_cols) h = combine_with_column(h, sponge_capacity(cols, n_cols));
+    return h;
+}
+
+// ChannelVar (primitives/channel/src/lib.rs:24-58)
+struct Channel {
+    Hash8 digest;
+    uint32_t n_sent;
+    __device__ void init() { digest = zero8(); n_sent = 0; }
+    __device__ void mix(const Hash8& left) { digest = perm_cap(left, digest); n_sent = 0; }
+    __device__ void mix_two(QM31 f, QM31 g) {
+        Hash8 l;
+        l.w[0] = f.a.a; l.w[1] = f.a.b; l.w[2] = f.b.a; l.w[3] = f.b.b;
+        l.w[4] = g.a.a; l.w[5] = g.a.b; l.w[6] = g.b.a; l.w[7] = g.b.b;
+        mix(l);
+    }
+    __device__ void mix_one(QM31 f) { mix_two(f, q_zero()); }
+    // returns the 8 rate words = two QM31
+    __device__ Hash8 draw() {
+        Hash8 l = zero8();
+        l.w[0] = n_sent++;
+        return perm_rate(l, digest);
+    }
+};
+__device__ __forceinline__ QM31 q_lo(const Hash8& h) { return q_mk(h.w[0], h.w[1], h.w[2], h.w[3]); }
+__device__ __forceinline__ QM31 q_hi(const Hash8& h) { return q_mk(h.w[4], h.w[5], h.w[6], h.w[7]); }
+
+__device__ __forceinline__ Hash8 load_hash(const uint32_t* p) {
+    Hash8 h;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        uint4 a = q[0], b = q[1];
+        h.w[0] = a.x; h.w[1] = a.y; h.w[2] = a.z; h.w[3] = a.w;
+        h.w[4] = b.x; h.w[5] = b.y; h.w[6] = b.z; h.w[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) h.w[i] = p[i];
+    }
+    return h;
+}
+__device__ __forceinline__ void store_hash(uint32_t* p, const Hash8& h) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = h.w[i];
+}
+
+}  // namespace rsv

@@ -1,0 +1,258 @@
+// rsv_hip.hip — the C-ABI of include/rsv.h implemented on HIP for gfx950.
+//
+// This translation unit is the whole product library (librsv_hip.so).  It
+// contains no CPU verification path: every entry point either runs the HIP
+// kernels or fails with RSV_E_DEVICE.
+#include "../../include/rsv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "primitives.hpp"
+#include "verify.hpp"
+
+using namespace rsv;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            if (getenv("RSV_DEBUG")) fprintf(stderr, "rsv: %s -> %s\n", #expr, hipGetErrorString(e_)); \
+            return RSV_E_DEVICE;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+struct VerifyState;                       // stage clock of the last verify call (verify_api.inc)
+void destroy_verify_state(VerifyState*);
+}  // namespace
+
+struct rsv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // reusable HBM workspace for rsv_verify_batch_dev
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    VerifyState* vs = nullptr;
+    rsv_public_input* d_pi = nullptr;
+    size_t d_pi_cap = 0;
+};
+
+namespace {
+
+// RAII device buffer for the host-pointer convenience entry points.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RSV_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RSV_E_DEVICE;
+    return RSV_OK;
+}
+
+inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int rsv_abi_version(void) { return RSV_ABI_VERSION; }
+
+int rsv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rsv_ctx_create(int device, rsv_ctx** out) {
+    if (!out) return RSV_E_NULL;
+    *out = nullptr;
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    rsv_ctx* c = new (std::nothrow) rsv_ctx();
+    if (!c) return RSV_E_DEVICE;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RSV_E_DEVICE;
+    }
+    *out = c;
+    return RSV_OK;
+}
+
+void rsv_ctx_destroy(rsv_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->vs) destroy_verify_state(c->vs);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_pi) (void)hipFree(c->d_pi);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rsv_ctx_synchronize(rsv_ctx* c) {
+    if (!c) return RSV_E_NULL;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSV_OK;
+}
+
+void* rsv_ctx_stream(rsv_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------- a3
+int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+    if (!c || (n && (!d_in || !d_out))) return RSV_E_NULL;
+    if (n == 0) return RSV_OK;
+    if (n > ((size_t)1 << 31)) return RSV_E_SIZE;
+    HIP_TRY(hipSetDevice(c->device));
+    // the range flag lives at the start of the workspace
+    if (c->ws_bytes < 256) {
+        if (c->ws) (void)hipFree(c->ws);
+        c->ws = nullptr; c->ws_bytes = 0;
+        HIP_TRY(hipMalloc(&c->ws, 1 << 20));
+        c->ws_bytes = 1 << 20;
+    }
+    uint32_t* bad = static_cast<uint32_t*>(c->ws);
+    hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint4*>(d_in), reinterpret_cast<uint4*>(d_out), n, bad);
+    HIP_TRY(hipGetLastError());
+    return RSV_OK;
+}
+
+int rsv_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n, int device) {
+    if (n && (!in16 || !out16)) return RSV_E_NULL;
+    if (n > ((size_t)1 << 28)) return RSV_E_SIZE;
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    if (n == 0) return RSV_OK;
+    DevBuf din, dout, dbad;
+    HIP_TRY(din.alloc(64 * n));
+    HIP_TRY(dout.alloc(64 * n));
+    HIP_TRY(dbad.alloc(4));
+    HIP_TRY(hipMemset(dbad.p, 0, 4));
+    HIP_TRY(hipMemcpy(din.p, in16, 64 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, 0, din.as<const uint4>(),
+                       dout.as<uint4>(), n, dbad.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, dbad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return RSV_E_RANGE;
+    HIP_TRY(hipMemcpy(out16, dout.p, 64 * n, hipMemcpyDeviceToHost));
+    return RSV_OK;
+}
+
+// ---------------------------------------------------------------- a4
+int rsv_poseidon2_half_permute(const uint32_t* left8, const uint32_t* right8, const uint8_t* swap,
+                               uint32_t* out_rate8, uint32_t* out_cap8, size_t n, int device) {
+    if (n && (!left8 || !right8)) return RSV_E_NULL;
+    if (n > ((size_t)1 << 28)) return RSV_E_SIZE;
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    if (n == 0) return RSV_OK;
+    DevBuf dl, dr, ds, drate, dcap, dbad;
+    HIP_TRY(dl.alloc(32 * n));
+    HIP_TRY(dr.alloc(32 * n));
+    HIP_TRY(dbad.alloc(4));
+    HIP_TRY(hipMemset(dbad.p, 0, 4));
+    HIP_TRY(hipMemcpy(dl.p, left8, 32 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, right8, 32 * n, hipMemcpyHostToDevice));
+    if (swap) {
+        HIP_TRY(ds.alloc(n));
+        HIP_TRY(hipMemcpy(ds.p, swap, n, hipMemcpyHostToDevice));
+    }
+    if (out_rate8) HIP_TRY(drate.alloc(32 * n));
+    if (out_cap8) HIP_TRY(dcap.alloc(32 * n));
+    hipLaunchKernelGGL(k_half_permute, dim3(grid_for(n, 256)), dim3(256), 0, 0, dl.as<const uint32_t>(),
+                       dr.as<const uint32_t>(), swap ? ds.as<const uint8_t>() : nullptr,
+                       out_rate8 ? drate.as<uint32_t>() : nullptr, out_cap8 ? dcap.as<uint32_t>() : nullptr, n,
+                       dbad.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, dbad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return RSV_E_RANGE;
+    if (out_rate8) HIP_TRY(hipMemcpy(out_rate8, drate.p, 32 * n, hipMemcpyDeviceToHost));
+    if (out_cap8) HIP_TRY(hipMemcpy(out_cap8, dcap.p, 32 * n, hipMemcpyDeviceToHost));
+    return RSV_OK;
+}
+
+// ---------------------------------------------------------------- a5
+int rsv_merkle_hash_node(const uint32_t* left8, const uint32_t* right8, const uint32_t* cols, size_t n_cols,
+                         uint32_t* out8, size_t n, int device) {
+    if (n && !out8) return RSV_E_NULL;
+    if ((left8 == nullptr) != (right8 == nullptr)) return RSV_E_NULL;
+    if (n_cols && !cols) return RSV_E_NULL;
+    if (!left8 && n_cols == 0) return RSV_E_SIZE;
+    if (n > ((size_t)1 << 26) || n_cols > 4096) return RSV_E_SIZE;
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    if (n == 0) return RSV_OK;
+    DevBuf dl, dr, dc, dout, dbad;
+    HIP_TRY(dbad.alloc(4));
+    HIP_TRY(hipMemset(dbad.p, 0, 4));
+    if (left8) {
+        HIP_TRY(dl.alloc(32 * n));
+        HIP_TRY(dr.alloc(32 * n));
+        HIP_TRY(hipMemcpy(dl.p, left8, 32 * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dr.p, right8, 32 * n, hipMemcpyHostToDevice));
+    }
+    if (n_cols) {
+        HIP_TRY(dc.alloc(4 * n_cols * n));
+        HIP_TRY(hipMemcpy(dc.p, cols, 4 * n_cols * n, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(dout.alloc(32 * n));
+    hipLaunchKernelGGL(k_hash_node, dim3(grid_for(n, 256)), dim3(256), 0, 0,
+                       left8 ? dl.as<const uint32_t>() : nullptr, left8 ? dr.as<const uint32_t>() : nullptr,
+                       n_cols ? dc.as<const uint32_t>() : nullptr, (uint32_t)n_cols, dout.as<uint32_t>(), n,
+                       dbad.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, dbad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return RSV_E_RANGE;
+    HIP_TRY(hipMemcpy(out8, dout.p, 32 * n, hipMemcpyDeviceToHost));
+    return RSV_OK;
+}
+
+// ---------------------------------------------------------------- a9
+int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint32_t* cols,
+                         const uint32_t* n_cols_at, uint32_t depth, uint32_t* out_root8, size_t n, int device) {
+    if (!query || !n_cols_at || !out_root8 || !cols || (depth && !sib8)) return RSV_E_NULL;
+    if (depth > 31 || n_cols_at[depth] == 0 || n > ((size_t)1 << 24)) return RSV_E_SIZE;
+    size_t per_path = 0;
+    for (uint32_t h = 0; h <= depth; h++) {
+        if (n_cols_at[h] > 4096) return RSV_E_SIZE;
+        per_path += n_cols_at[h];
+    }
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    if (n == 0) return RSV_OK;
+    DevBuf dq, ds, dc, dn, dout;
+    HIP_TRY(dq.alloc(4 * n));
+    HIP_TRY(ds.alloc(32 * (size_t)depth * n));
+    HIP_TRY(dc.alloc(4 * per_path * n));
+    HIP_TRY(dn.alloc(4 * (depth + 1)));
+    HIP_TRY(dout.alloc(32 * n));
+    HIP_TRY(hipMemcpy(dq.p, query, 4 * n, hipMemcpyHostToDevice));
+    if (depth) HIP_TRY(hipMemcpy(ds.p, sib8, 32 * (size_t)depth * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc.p, cols, 4 * per_path * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dn.p, n_cols_at, 4 * (depth + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_path_root, dim3(grid_for(n, 256)), dim3(256), 0, 0, dq.as<const uint32_t>(),
+                       ds.as<const uint32_t>(), dc.as<const uint32_t>(), dn.as<const uint32_t>(), depth,
+                       (uint32_t)per_path, dout.as<uint32_t>(), n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_root8, dout.p, 32 * n, hipMemcpyDeviceToHost));
+    return RSV_OK;
+}
+
+}  // extern "C"
+
+#include "verify_api.inc"

@@ -1,0 +1,1002 @@
+// verify.hpp — the batch verification pipeline for Poseidon31-channel
+// Plonk-with-Poseidon Circle-STARK proofs, as HIP kernels for gfx950.
+//
+// Stage            kernel            parallelism                reference
+// ---------------  ----------------  -------------------------  ----------------------------------------
+// wire format      k_parse           1 lane / proof             bincode of PlonkWithPoseidonProof
+// canonicity       k_scan            1 wave / proof, 16 B/lane  (M31 words must be < P)
+// transcript       k_transcript      1 lane / proof             components/recursive/fiat_shamir/src/lib.rs:31-176
+// OODS identity    k_oods            1 lane / proof             components/recursive/composition/src/**
+// decommit plan    k_plan            1 lane / proof             components/hints/src/decommit.rs:53-142, folding.rs:107-212
+// quotients+folds  k_query           1 lane / (proof, query)    components/recursive/answer/src/**, folding/src/lib.rs:57-204
+// trace trees      k_trace_merkle    1 lane / (proof,tree,query) components/recursive/data_structures/src/lib.rs:315-354
+// FRI trees        k_pair_merkle     1 lane / (proof,layer,query) components/recursive/data_structures/src/lib.rs:400-464
+// verdict          k_finalize        1 lane / proof             accept bit + first failing stage
+//
+// The Merkle kernels follow the reference's per-query form: every lane walks
+// one authentication path from its leaf to the root, one Poseidon2 permutation
+// per level.  Sibling hashes that the reference's host code re-derives from
+// other query paths (SinglePathMerkleProof::from_stwo_proof) are exchanged
+// between the lanes of a proof through LDS; the remaining ones are gathered
+// straight from the proof's hash_witness at the index given by the plan.
+#pragma once
+#include "circle.hpp"
+#include "layout.hpp"
+#include "merkle.hpp"
+
+namespace rsv {
+
+__constant__ SampleTable SAMPLES = make_sample_table();
+
+enum : uint32_t {
+    R_OK = 0, R_PARSE = 1, R_POW = 2, R_LOGUP = 3, R_COMPOSITION = 4, R_DUP_QUERY = 5, R_MERKLE_T0 = 6,
+    R_FRI_FIRST = 10, R_FRI_INNER = 11, R_FRI_LAST = 12
+};
+
+struct PubInput {
+    uint32_t idx;
+    uint32_t value[4];
+};
+
+struct CfgOpt {
+    uint32_t present, pow_bits, blowup, log_last, nq;
+};
+
+__device__ __forceinline__ QM31 ldq(const uint32_t* p) { return q_mk(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ void stq(uint32_t* p, QM31 v) { p[0] = v.a.a; p[1] = v.a.b; p[2] = v.b.a; p[3] = v.b.b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------ k_parse
+// Walks the length prefixes of one proof and records where every section lives.
+struct WordReader {
+    const uint32_t* w;
+    uint32_t n, pos;
+    bool ok;
+    __device__ uint32_t u32() {
+        if (!ok || pos >= n) { ok = false; return 0; }
+        return w[pos++];
+    }
+    // u64 that must fit 32 bits
+    __device__ uint32_t len() {
+        uint32_t lo = u32(), hi = u32();
+        if (hi != 0) ok = false;
+        return lo;
+    }
+    __device__ uint32_t skip(uint32_t words) {
+        uint32_t at = pos;
+        if (!ok || words > n - pos) { ok = false; return at; }
+        pos += words;
+        return at;
+    }
+};
+
+__device__ inline void parse_decommit(WordReader& r, uint32_t& off, uint32_t& cnt) {
+    cnt = r.len();
+    if (cnt > (1u << 20)) r.ok = false;
+    off = r.skip(r.ok ? 8u * cnt : 0u);
+    if (r.len() != 0) r.ok = false;  // column_witness must be empty (components/hints/src/decommit.rs:71)
+}
+__device__ inline void parse_fri_layer(WordReader& r, FriLayerRef& l) {
+    l.wit_n = r.len();
+    if (l.wit_n > (1u << 20)) r.ok = false;
+    l.wit_off = r.skip(r.ok ? 4u * l.wit_n : 0u);
+    parse_decommit(r, l.hash_off, l.hash_n);
+    l.commit_off = r.skip(8);
+}
+
+__global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                              uint32_t n, CfgOpt cfg, ProofMeta* __restrict__ metas,
+                                              ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ summary) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    ProofMeta& m = metas[p];
+    ctxs[p].flags = 0;
+    uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    m.reason = R_PARSE;
+    m.nq = 0; m.M = 0; m.n_inner = 0;
+    if (o1 < o0 || ((o0 | o1) & 3) || (o1 - o0) > (1ull << 30)) return;
+    WordReader r{reinterpret_cast<const uint32_t*>(blob + o0), (uint32_t)((o1 - o0) >> 2), 0, true};
+    m.n_words = r.n;
+    if (r.n < SAMPLES.end + 8) return;
+    m.lp = r.w[W_LP]; m.lq = r.w[W_LQ];
+    m.pow_bits = r.w[W_POW_BITS]; m.blowup = r.w[W_BLOWUP]; m.log_last = r.w[W_LOG_LAST];
+    uint32_t nq = r.w[W_NQ];
+    if (r.w[W_NQ + 1] != 0 || nq == 0 || nq > MAXQ) return;
+    if (cfg.present && (cfg.pow_bits != m.pow_bits || cfg.blowup != m.blowup || cfg.log_last != m.log_last || cfg.nq != nq))
+        return;
+    uint32_t b = m.blowup, last = m.log_last;
+    if (m.lp < 1 || m.lq < 1 || m.lp > 28 || m.lq > 28 || b < 1 || b > 16 || last > 16 || m.pow_bits > 30) return;
+    uint32_t A = m.lp + b, B = m.lq + b, M = umax(m.lp + 1, m.lq + 2) + b;
+    if (M > MAX_LOG) return;
+    if (A < last + b + 1 || B < last + b + 1) return;
+    if (r.w[W_NCOMMIT] != 4 || r.w[W_NCOMMIT + 1] != 0 || r.w[W_NTREES] != 4 || r.w[W_NTREES + 1] != 0) return;
+    // constant-shape sampled_values: 4 trees of 50/60/16/8 columns with 1 or 2 mask points
+    uint32_t c_all = 0;
+    bool ok = true;
+    for (int t = 0; t < 4; t++) {
+        ok &= r.w[SAMPLES.tree_prefix[t]] == tree_cols(t) && r.w[SAMPLES.tree_prefix[t] + 1] == 0;
+        for (uint32_t c = 0; c < tree_cols(t); c++, c_all++)
+            ok &= r.w[SAMPLES.col_prefix[c_all]] == n_samples_of(t, (int)c) && r.w[SAMPLES.col_prefix[c_all] + 1] == 0;
+    }
+    if (!ok) return;
+    r.pos = SAMPLES.end;
+    if (r.len() != 4) return;
+    for (int t = 0; t < 4; t++) parse_decommit(r, m.hw_off[t], m.hw_n[t]);
+    if (r.len() != 4) return;
+    for (int t = 0; t < 4; t++) {
+        m.qv_n[t] = r.len();
+        if (m.qv_n[t] > (1u << 22)) r.ok = false;
+        m.qv_off[t] = r.skip(r.ok ? m.qv_n[t] : 0u);
+    }
+    m.nonce_off = r.skip(2);
+    parse_fri_layer(r, m.first);
+    uint32_t n_inner = r.len();
+    if (!r.ok || n_inner != M - 1 - (last + b) || n_inner > MAX_INNER) return;
+    for (uint32_t i = 0; i < n_inner; i++) parse_fri_layer(r, m.inner[i]);
+    m.last_n = r.len();
+    if (!r.ok || m.last_n != (1u << last)) return;  // components/hints/src/fiat_shamir.rs:195-198
+    m.last_off = r.skip(4u * m.last_n);
+    (void)r.u32();  // last_layer_poly.log_size
+    if (!r.ok || r.pos != r.n) return;
+    m.nq = nq; m.n_inner = n_inner; m.A = A; m.B = B; m.M = M;
+    m.reason = R_OK;
+    atomicMax(&summary[0], nq);
+    atomicMax(&summary[1], M);
+    atomicMax(&summary[2], n_inner);
+}
+
+// ------------------------------------------------------------------- k_scan
+// Every field element of a proof must be a canonical M31 word (< P); the only
+// words exempt are the two halves of the proof-of-work nonce.  One wave per
+// proof reads the proof once with 16-byte coalesced loads — this pass is the
+// "proof bytes read once" leg of the HBM roofline.
+__global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                              uint32_t n, ProofMeta* __restrict__ metas) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    ProofMeta& m = metas[wave];
+    if (m.reason != R_OK) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[wave]);
+    uint32_t nw = m.n_words, nonce = m.nonce_off;
+    uint32_t bad = 0;
+    // align the vector loop to 16 bytes
+    uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
+    head = umin(head, nw);
+    if (lane < head) bad |= (w[lane] >= P) && lane != nonce && lane != nonce + 1;
+    const uint4* v = reinterpret_cast<const uint4*>(w + head);
+    uint32_t nv = (nw - head) >> 2;
+    for (uint32_t i = lane; i < nv; i += 64) {
+        uint4 x = v[i];
+        uint32_t base = head + 4 * i;
+        uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
+        if (o) {
+            for (int k = 0; k < 4; k++)
+                if (((o >> k) & 1) && base + k != nonce && base + k != nonce + 1) bad = 1;
+        }
+    }
+    uint32_t tail = head + 4 * nv;
+    if (tail + lane < nw) bad |= (w[tail + lane] >= P) && (tail + lane) != nonce && (tail + lane) != nonce + 1;
+    if (__any(bad) && lane == 0) m.reason = R_PARSE;
+}
+
+// ------------------------------------------------------------- k_transcript
+// FiatShamirResults::compute (components/recursive/fiat_shamir/src/lib.rs:44-130):
+// a strictly sequential chain of channel permutations per proof.
+__global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                   uint32_t n, const ProofMeta* __restrict__ metas,
+                                                   ProofCtx* __restrict__ ctxs) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    Channel ch;
+    ch.init();
+    Hash8 d;
+    ch.mix(load_hash(w + W_COMMIT0));
+    ch.mix_one(q_from_m(m.lp));  // statement 0: data_structures/src/lib.rs:52-55
+    ch.mix_one(q_from_m(m.lq));
+    ch.mix(load_hash(w + W_COMMIT0 + 8));
+    d = ch.draw();  // lookup elements z, alpha: data_structures/src/lib.rs:242-245
+    stq(c.z, q_lo(d)); stq(c.alpha, q_hi(d));
+    ch.mix_two(ldq(w + W_PLONK_SUM), ldq(w + W_POSEIDON_SUM));  // statement 1: data_structures/src/lib.rs:85-87
+    ch.mix(load_hash(w + W_COMMIT0 + 16));
+    d = ch.draw();
+    stq(c.rc, q_lo(d));
+    ch.mix(load_hash(w + W_COMMIT0 + 24));
+    d = ch.draw();
+    QM31 t = q_lo(d);
+    stq(c.oods_t, t);
+    {  // CirclePointQM31Var::from_t (primitives/circle/src/lib.rs:204-219)
+        QM31 t2 = q_mul(t, t);
+        QM31 inv = q_inv(q_add(t2, q_one()));
+        stq(c.oods_x, q_mul(q_sub(q_one(), t2), inv));
+        stq(c.oods_y, q_mul(q_dbl(t), inv));
+    }
+#pragma unroll 1
+    for (int k = 0; k < N_SAMPLES; k += 2)  // fiat_shamir/src/lib.rs:68-75
+        ch.mix_two(ldq(w + SAMPLES.off[k]), ldq(w + SAMPLES.off[k + 1]));
+    d = ch.draw();
+    stq(c.after, q_lo(d));
+    ch.mix(load_hash(w + m.first.commit_off));
+    d = ch.draw();
+    stq(c.fri_alpha[0], q_lo(d));
+#pragma unroll 1
+    for (uint32_t i = 0; i < m.n_inner; i++) {
+        ch.mix(load_hash(w + m.inner[i].commit_off));
+        d = ch.draw();
+        stq(c.fri_alpha[i + 1], q_lo(d));
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < m.last_n; i += 2) {  // fiat_shamir/src/lib.rs:94-100
+        const uint32_t* cf = w + m.last_off + 4 * i;
+        if (i + 1 < m.last_n) ch.mix_two(ldq(cf), ldq(cf + 4));
+        else ch.mix_one(ldq(cf));
+    }
+    // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
+    uint64_t nonce = (uint64_t)w[m.nonce_off] | ((uint64_t)w[m.nonce_off + 1] << 32);
+    ch.mix_one(q_mk((uint32_t)(nonce & ((1u << 22) - 1)), (uint32_t)((nonce >> 22) & ((1u << 21) - 1)),
+                    (uint32_t)((nonce >> 43) & ((1u << 21) - 1)), 0));
+    store_hash(c.pow_digest, ch.digest);
+    uint32_t flags = 0;
+    if (ch.digest.w[0] & ((1u << m.pow_bits) - 1u)) flags |= 1u << R_POW;  // fiat_shamir/src/lib.rs:115-117
+    uint32_t got = 0;  // fiat_shamir/src/lib.rs:119-130
+#pragma unroll 1
+    while (got < m.nq) {
+        d = ch.draw();
+        for (int k = 0; k < 8 && got < m.nq; k++) c.raw_q[got++] = d.w[k];
+    }
+    c.flags = flags;
+}
+
+// ------------------------------------------------------------------- k_oods
+// Logup total-sum check (fiat_shamir/src/lib.rs:133-141) and the OODS
+// composition identity (components/recursive/composition/src/**).
+struct EvalCtx {
+    QM31 rc, acc, dinv, z, alpha, alpha2, shift;
+    QM31 fp[5], fq[5];
+    int n_fracs;
+    const uint32_t* w;
+    int inter;  // next interaction sample index
+    __device__ QM31 smp(int k) const { return ldq(w + SAMPLES.off[k]); }
+    // data_structures.rs:26-28,166-169
+    __device__ void constraint(QM31 v) { acc = q_add(q_mul(acc, rc), q_mul(v, dinv)); }
+    // data_structures.rs:147-164
+    __device__ void relation(QM31 mult, QM31 v0, QM31 v1) {
+        fp[n_fracs] = mult;
+        fq[n_fracs++] = q_sub(q_add(v0, q_mul(alpha, v1)), z);
+    }
+    __device__ void relation(QM31 mult, QM31 v0, QM31 v1, QM31 v2) {
+        fp[n_fracs] = mult;
+        fq[n_fracs++] = q_sub(q_add(q_add(v0, q_mul(alpha, v1)), q_mul(alpha2, v2)), z);
+    }
+    // data_structures.rs:171-210
+    __device__ void finalize_logup(int batch) {
+        int n_batches = (n_fracs + batch - 1) / batch;
+        QM31 prev = q_zero();
+        for (int bi = 0; bi < n_batches; bi++) {
+            int lo = bi * batch, hi = lo + batch < n_fracs ? lo + batch : n_fracs;
+            QM31 pp = fp[lo], qq = fq[lo];
+            for (int k = lo + 1; k < hi; k++) {
+                pp = q_add(q_mul(pp, fq[k]), q_mul(fp[k], qq));
+                qq = q_mul(qq, fq[k]);
+            }
+            if (bi < n_batches - 1) {
+                QM31 cur = q_combine_ef(smp(inter), smp(inter + 1), smp(inter + 2), smp(inter + 3));
+                inter += 4;
+                constraint(q_sub(q_mul(q_sub(cur, prev), qq), pp));
+                prev = cur;
+            } else {
+                QM31 prev_row = q_combine_ef(smp(inter), smp(inter + 2), smp(inter + 4), smp(inter + 6));
+                QM31 cur = q_combine_ef(smp(inter + 1), smp(inter + 3), smp(inter + 5), smp(inter + 7));
+                inter += 8;
+                QM31 diff = q_sub(q_sub(cur, prev_row), prev);
+                constraint(q_sub(q_mul(q_add(diff, shift), qq), pp));
+            }
+        }
+    }
+};
+
+__device__ inline QM31 q_double_x(QM31 x, uint32_t times) {
+#pragma unroll 1
+    for (uint32_t i = 0; i < times; i++) x = q_sub(q_dbl(q_mul(x, x)), q_one());
+    return x;
+}
+__device__ __forceinline__ QM31 q_pow5(QM31 x) {
+    QM31 x2 = q_mul(x, x);
+    return q_mul(q_mul(x2, x2), x);
+}
+// poseidon.rs:12-71 over QM31
+__device__ inline void q_m4(QM31* x) {
+    QM31 t0 = q_add(x[0], x[1]), t02 = q_dbl(t0), t1 = q_add(x[2], x[3]), t12 = q_dbl(t1);
+    QM31 t2 = q_add(q_dbl(x[1]), t1), t3 = q_add(q_dbl(x[3]), t0);
+    QM31 t4 = q_add(q_dbl(t12), t3), t5 = q_add(q_dbl(t02), t2);
+    x[0] = q_add(t3, t5); x[1] = t5; x[2] = q_add(t2, t4); x[3] = t4;
+}
+__device__ __noinline__ void q_external(QM31* s) {
+    for (int g = 0; g < 4; g++) q_m4(s + 4 * g);
+    for (int j = 0; j < 4; j++) {
+        QM31 sum = q_add(q_add(s[j], s[j + 4]), q_add(s[j + 8], s[j + 12]));
+        for (int g = 0; g < 4; g++) s[4 * g + j] = q_add(s[4 * g + j], sum);
+    }
+}
+__device__ __noinline__ void q_internal(QM31* s) {
+    QM31 sum = s[0];
+    for (int i = 1; i < 16; i++) sum = q_add(sum, s[i]);
+    s[0] = q_add(s[0], q_add(q_dbl(s[0]), sum));
+    for (int i = 1; i < 16; i++) s[i] = q_add(q_mul_m(s[i], 1u << (i + 1)), sum);
+}
+
+__global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                             uint32_t n, const ProofMeta* __restrict__ metas,
+                                             ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
+                                             uint32_t n_pi) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    uint32_t flags = 0;
+    QM31 z = ldq(c.z), alpha = ldq(c.alpha), plonk_sum = ldq(w + W_PLONK_SUM), poseidon_sum = ldq(w + W_POSEIDON_SUM);
+    {  // fiat_shamir/src/lib.rs:133-141
+        QM31 sum = q_zero();
+        for (uint32_t i = 0; i < n_pi; i++) {
+            QM31 dnm = q_sub(q_add(ldq(pi[i].value), q_mul_m(alpha, pi[i].idx % P)), z);
+            sum = q_add(sum, q_inv(dnm));
+        }
+        if (!q_eq(q_add(q_add(sum, poseidon_sum), plonk_sum), q_zero())) flags |= 1u << R_LOGUP;
+    }
+    EvalCtx e;
+    e.rc = ldq(c.rc); e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
+    QM31 ox = ldq(c.oods_x);
+    const QM31 one = q_one();
+    {  // plonk.rs:8-82 — preprocessed samples 0..10, trace samples 50..62, interaction samples 110..122
+        e.dinv = q_inv(q_double_x(ox, m.lp - 1));  // coset_vanishing: composition/src/lib.rs:18-29
+        e.shift = q_mul_m(plonk_sum, m_inv(1u << m.lp));  // data_structures.rs:67-68
+        e.inter = S_T2; e.n_fracs = 0;
+        const int pre = S_T0, tr = S_T1;
+        QM31 enforce = e.smp(pre + 9), op = e.smp(pre + 3);
+        e.constraint(q_mul(enforce, e.smp(tr + 9)));
+        e.constraint(q_mul(enforce, e.smp(tr + 10)));
+        e.constraint(q_mul(enforce, e.smp(tr + 11)));
+        QM31 a = q_combine_ef(e.smp(tr + 0), e.smp(tr + 1), e.smp(tr + 2), e.smp(tr + 3));
+        QM31 b = q_combine_ef(e.smp(tr + 4), e.smp(tr + 5), e.smp(tr + 6), e.smp(tr + 7));
+        QM31 cc = q_combine_ef(e.smp(tr + 8), e.smp(tr + 9), e.smp(tr + 10), e.smp(tr + 11));
+        e.constraint(q_sub(q_sub(cc, q_mul(op, q_add(a, b))), q_mul(q_mul(q_sub(one, op), a), b)));
+        e.relation(e.smp(pre + 4), a, e.smp(pre + 0));
+        e.relation(e.smp(pre + 5), b, e.smp(pre + 1));
+        e.relation(e.smp(pre + 6), cc, e.smp(pre + 2));
+        e.relation(q_neg(e.smp(pre + 8)), e.smp(pre + 7), a, b);
+        e.finalize_logup(2);
+    }
+    {  // poseidon.rs:73-241 — preprocessed 10..50, trace 62..110, interaction samples 122..134
+        e.dinv = q_inv(q_double_x(ox, m.lq - 1));
+        e.shift = q_mul_m(poseidon_sum, m_inv(1u << m.lq));
+        e.inter = S_T2 + 12; e.n_fracs = 0;
+        const int pre = S_T0 + 10, in = S_T1 + 12, mid = in + 16, out = in + 32;
+        const int rc0 = pre + 4, rc1 = pre + 20;
+        QM31 is_first = e.smp(pre), is_last = e.smp(pre + 1), is_full = e.smp(pre + 2), round_id = e.smp(pre + 3);
+        QM31 not_first = q_sub(one, is_first), not_last = q_sub(one, is_last), is_partial = q_sub(not_first, is_full);
+        QM31 swap_val = e.smp(mid), one_minus_swap = q_sub(one, swap_val);
+        QM31 st[16];
+        for (int i = 0; i < 16; i++) {
+            QM31 lo = e.smp(in + (i & 7)), hi = e.smp(in + (i & 7) + 8);
+            st[i] = i < 8 ? q_add(q_mul(lo, one_minus_swap), q_mul(hi, swap_val))
+                          : q_add(q_mul(lo, swap_val), q_mul(hi, one_minus_swap));
+        }
+        q_external(st);
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_first, q_sub(st[i], e.smp(out + i))));
+        for (int i = 0; i < 16; i++) {
+            QM31 full = q_pow5(q_add(e.smp(in + i), e.smp(rc0 + i)));
+            QM31 mi = e.smp(mid + i);
+            e.constraint(q_mul(is_full, q_sub(mi, full)));
+            st[i] = mi;
+        }
+        q_external(st);
+        for (int i = 0; i < 16; i++) st[i] = q_pow5(q_add(st[i], e.smp(rc1 + i)));
+        q_external(st);
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_full, q_sub(e.smp(out + i), st[i])));
+        for (int i = 0; i < 16; i++) st[i] = e.smp(in + i);
+#pragma unroll 1
+        for (int r = 0; r < 14; r++) {
+            QM31 v = q_pow5(q_add(st[0], e.smp(rc0 + r)));
+            QM31 mi = e.smp(mid + r);
+            e.constraint(q_mul(is_partial, q_sub(mi, v)));
+            st[0] = mi;
+            q_internal(st);
+        }
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_partial, q_sub(e.smp(out + i), st[i])));
+        QM31 ext1 = e.smp(pre + 36), ext2 = e.smp(pre + 37), ext1_nz = e.smp(pre + 38), ext2_nz = e.smp(pre + 39);
+        QM31 in_left = q_dbl(round_id), in_right = q_add(in_left, one), out_left = q_add(in_right, one),
+             out_right = q_add(out_left, one);
+#define EF4(base) q_combine_ef(e.smp(base), e.smp((base) + 1), e.smp((base) + 2), e.smp((base) + 3))
+        e.relation(q_sub(q_mul(ext1_nz, is_first), not_first), q_add(q_mul(is_first, ext1), q_mul(not_first, in_left)),
+                   EF4(in), EF4(in + 4));
+        e.relation(q_sub(q_mul(ext2_nz, is_first), not_first), q_add(q_mul(is_first, ext2), q_mul(not_first, in_right)),
+                   EF4(in + 8), EF4(in + 12));
+        e.relation(q_add(q_mul(ext1_nz, is_last), not_last), q_add(q_mul(is_last, ext1), q_mul(not_last, out_left)),
+                   EF4(out), EF4(out + 4));
+        e.relation(q_add(q_mul(ext2_nz, is_last), not_last), q_add(q_mul(is_last, ext2), q_mul(not_last, out_right)),
+                   EF4(out + 8), EF4(out + 12));
+#undef EF4
+        e.relation(q_mul(is_first, not_last), swap_val, e.smp(rc0));
+        e.finalize_logup(3);
+    }
+    {  // composition/src/lib.rs:106-120
+        QM31 left = q_combine_ef(e.smp(S_T3), e.smp(S_T3 + 1), e.smp(S_T3 + 2), e.smp(S_T3 + 3));
+        QM31 right = q_combine_ef(e.smp(S_T3 + 4), e.smp(S_T3 + 5), e.smp(S_T3 + 6), e.smp(S_T3 + 7));
+        uint32_t bound = umax(m.lp + 2, m.lq + 3);
+        QM31 expected = q_add(left, q_mul(right, q_double_x(ox, bound - 2)));
+        if (!q_eq(e.acc, expected)) flags |= 1u << R_COMPOSITION;
+    }
+    if (flags) atomicOr(&c.flags, flags);
+}
+
+// ------------------------------------------------------------------- k_plan
+// Sorts the query positions, derives the decommitment plan (who owns which
+// sibling, which witness index each lane consumes; see layout.hpp) and the
+// per-proof constants of the DEEP quotients
+// (components/recursive/answer/src/data_structures.rs:132-189).
+struct PlanPtrs {
+    PlanHdr* hdr;
+    uint32_t* ent;  // [n][(maxM+1) * G]
+    uint32_t* fl;   // [n][2 * G]
+    uint32_t G, maxM;
+};
+
+__device__ inline int sample_index(int t, int col, int s) {
+    if (t == 0) return S_T0 + col;
+    if (t == 1) return S_T1 + col;
+    if (t == 3) return S_T3 + col;
+    return S_T2 + (col < 4 ? col : col < 8 ? 4 + 2 * (col - 4) + s : col < 12 ? 12 + (col - 8) : 16 + 2 * (col - 12) + s);
+}
+
+__global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                             uint32_t n, const ProofMeta* __restrict__ metas,
+                                             ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const uint32_t nq = m.nq, M = m.M, A = m.A, B = m.B, G = pl.G;
+    uint32_t flags = 0;
+    // query positions (primitives/query/src/lib.rs:19-38), sorted ascending
+    for (uint32_t j = 0; j < nq; j++) {
+        uint32_t v = c.raw_q[j] & ((1u << M) - 1u);
+        uint32_t k = j;
+        while (k > 0 && c.q[k - 1] > v) { c.q[k] = c.q[k - 1]; k--; }
+        c.q[k] = v;
+    }
+    for (uint32_t j = 0; j + 1 < nq; j++)
+        if (c.q[j] == c.q[j + 1]) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
+    // column log sizes, descending
+    uint32_t n_sizes = 0;
+    c.sizes[n_sizes++] = M;
+    if (A == B) c.sizes[n_sizes++] = A;
+    else { c.sizes[n_sizes++] = umax(A, B); c.sizes[n_sizes++] = umin(A, B); }
+    c.n_sizes = n_sizes;
+    if (n_sizes < 3) c.sizes[2] = 0;
+
+    PlanHdr& h = pl.hdr[p];
+    uint32_t* ent = pl.ent + (size_t)p * (pl.maxM + 1) * G;
+    uint32_t* fl = pl.fl + (size_t)p * 2 * G;
+    // generic tables, node level l = M .. 1 (children of level l-1)
+    uint32_t suffix = 0;
+    h.lvl[M + 1] = 0;
+    for (uint32_t l = M; l >= 1; l--) {
+        uint32_t sh = M - l;  // node = q >> sh
+        uint32_t k = 0, nodes_before = 0, runs_lacking = 0;
+        while (k < nq) {
+            uint32_t a = k;
+            int split = -1;
+            while (k + 1 < nq) {
+                uint32_t x = c.q[k] ^ c.q[k + 1];
+                int d = x ? 31 - __clz(x) : -1;
+                if (d > (int)sh) break;
+                if (d == (int)sh) split = (int)k;
+                k++;
+            }
+            uint32_t bnd = k;
+            k++;
+            bool both = split >= 0;
+            for (uint32_t j = a; j <= bnd; j++) {
+                bool right = both && (int)j > split;
+                uint32_t rb = nodes_before + (right ? 1u : 0u);
+                uint32_t sib = both ? (right ? (uint32_t)split : (uint32_t)split + 1u) : 0xFFu;
+                ent[l * G + j] = rb | (runs_lacking << 8) | (sib << 16);
+            }
+            nodes_before += both ? 2u : 1u;
+            runs_lacking += both ? 0u : 1u;
+        }
+        suffix += runs_lacking;
+        h.lvl[l] = nodes_before | (runs_lacking << 8) | (suffix << 16);
+    }
+    for (uint32_t j = 0; j < nq; j++) ent[j] = 0xFFu << 16;
+    h.lvl[0] = 1u | (suffix << 16);
+    // first-layer fri_witness bases (components/hints/src/folding.rs:414-451)
+    {
+        uint32_t base = 0;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            c.fw_base[g] = base;
+            base += (h.lvl[c.sizes[g]] >> 8) & 0xFFu;
+        }
+        if (base != m.first.wit_n) flags |= 1u << R_FRI_FIRST;
+    }
+    // first-layer pair tree hash-witness plan (components/hints/src/folding.rs:107-206)
+    {
+        uint32_t wcount = 0, dslot = 0;
+        for (uint32_t l = M; l-- > 0;) {
+            h.wf[l + 1] = (uint16_t)wcount;
+            bool child_data = false, data = false;
+            for (uint32_t g = 0; g < n_sizes; g++) { child_data |= c.sizes[g] == l + 1; data |= c.sizes[g] == l; }
+            uint32_t sh = M - l;
+            uint32_t k = 0;
+            while (k < nq) {
+                uint32_t a = k;
+                uint32_t node = c.q[k] >> sh;
+                bool has_both_children = false;
+                while (k + 1 < nq && (c.q[k + 1] >> sh) == node) {
+                    if (((c.q[k] >> (sh - 1)) ^ (c.q[k + 1] >> (sh - 1))) & 1u) has_both_children = true;
+                    k++;
+                }
+                uint32_t bnd = k;
+                k++;
+                uint32_t lack = (!child_data && !has_both_children) ? 1u : 0u;
+                if (data) {
+                    bool sib_present = (a > 0 && (c.q[a - 1] >> sh) == (node ^ 1u)) ||
+                                       (bnd + 1 < nq && (c.q[bnd + 1] >> sh) == (node ^ 1u));
+                    uint32_t w_self = 0xFFFFu, w_sib = 0xFFFFu;
+                    if (node & 1u) {
+                        if (!sib_present) { w_sib = wcount; wcount += 2; }
+                        if (lack) { w_self = wcount; wcount += 1; }
+                    } else {
+                        if (lack) { w_self = wcount; wcount += 1; }
+                        if (!sib_present) { w_sib = wcount; wcount += 2; }
+                    }
+                    if (dslot < 2)
+                        for (uint32_t j = a; j <= bnd; j++) fl[dslot * G + j] = w_self | (w_sib << 16);
+                } else {
+                    wcount += lack;
+                }
+            }
+            if (data) dslot++;
+        }
+        h.wf[0] = (uint16_t)wcount;
+        h.wf_total = (uint16_t)umin(wcount, 0xFFFFu);
+    }
+    // quotient constants: alpha_k = -2u * after^k (data_structures.rs:162-189)
+    QM31 after = ldq(c.after);
+    {
+        QM31 ak = q_mk(0, 0, m_neg(2), 0);
+#pragma unroll 1
+        for (int k = 0; k < N_APOW; k++) { stq(c.apow[k], ak); ak = q_mul(ak, after); }
+    }
+    QM31 ox = ldq(c.oods_x), oy = ldq(c.oods_y);
+    for (uint32_t g = 0; g < n_sizes; g++) {
+        uint32_t l = c.sizes[g];
+        // batch 0: OODS point; batch 1: OODS - g_{component log size} (answer/src/lib.rs:62-72)
+        uint32_t comp_log = (l == A) ? m.lp : m.lq;
+        CPoint step = cp_gen_mul(1u << (31u - comp_log));
+        step.y = m_neg(step.y);
+        QM31 sx = q_sub(q_mul_m(ox, step.x), q_mul_m(oy, step.y));
+        QM31 sy = q_add(q_mul_m(ox, step.y), q_mul_m(oy, step.x));
+        uint32_t k_run = 0, n_batches = (l == M) ? 1u : 2u;
+        for (uint32_t bi = 0; bi < n_batches; bi++) {
+            QM31 px = bi ? sx : ox, py = bi ? sy : oy;
+            QM31 sa = q_zero(), sb = q_zero();
+            for (int t = 0; t < 4; t++) {
+                uint32_t c0, c1;
+                if (l == M) { if (t != 3) continue; c0 = 0; c1 = 8; }
+                else {
+                    if (t == 3) continue;
+                    c0 = (l == A) ? 0u : plonk_cols(t);
+                    c1 = (l == B) ? tree_cols(t) : plonk_cols(t);
+                }
+                for (uint32_t col = c0; col < c1; col++) {
+                    uint32_t ns = n_samples_of(t, (int)col);
+                    if (bi == 1 && ns != 2) continue;
+                    int si = sample_index(t, (int)col, bi == 1 ? 0 : (int)ns - 1);
+                    QM31 v = ldq(w + SAMPLES.off[si]);
+                    QM31 ak = ldq(c.apow[k_run++]);
+                    // complex_conjugate_line_coeffs_var (data_structures.rs:132-160)
+                    sa = q_add(sa, q_mul_c(ak, v.b));
+                    sb = q_add(sb, q_mul_c(ak, c_sub(c_mul(v.a, py.b), c_mul(v.b, py.a))));
+                }
+            }
+            QBatch& qb = c.batch[g][bi];
+            stq(qb.sa, sa); stq(qb.sb, sb);
+            qb.prx[0] = px.a.a; qb.prx[1] = px.a.b; qb.pix[0] = px.b.a; qb.pix[1] = px.b.b;
+            qb.pry[0] = py.a.a; qb.pry[1] = py.a.b; qb.piy[0] = py.b.a; qb.piy[1] = py.b.b;
+        }
+        c.n_batches[g] = n_batches;
+    }
+    if (flags) atomicOr(&c.flags, flags);
+}
+
+// ------------------------------------------------------------------ k_query
+// One lane per (proof, query): DEEP quotients for every column log size
+// (answer/src/lib.rs:260-315,356-382), the circle->line fold of the first FRI
+// layer (folding/src/lib.rs:57-90), the line folds of the inner layers
+// (:120-192) and the last-layer polynomial check (:194-204).  Values owned by
+// other queries of the same proof (pair siblings) are exchanged through LDS.
+// Writes, for the Merkle kernels, the (self, sibling) leaf values of every FRI tree.
+struct QueryArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n;
+    const ProofMeta* metas;
+    ProofCtx* ctxs;
+    PlanPtrs pl;
+    uint32_t* leafv;  // [n][3 + maxInner][G][8]
+    uint32_t maxInner;
+};
+
+__device__ __forceinline__ uint32_t ent_rb(uint32_t e) { return e & 0xFFu; }
+__device__ __forceinline__ uint32_t ent_lb(uint32_t e) { return (e >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t ent_sib(uint32_t e) { return (e >> 16) & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_nd(uint32_t v) { return v & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_tl(uint32_t v) { return (v >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_s(uint32_t v) { return v >> 16; }
+
+__device__ inline QM31 fold_pair(QM31 self, QM31 sib, bool odd, uint32_t inv_coord, QM31 alpha) {
+    QM31 l = odd ? sib : self, r = odd ? self : sib;
+    return q_add(q_add(l, r), q_mul(q_mul_m(q_sub(l, r), inv_coord), alpha));
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
+    __shared__ uint32_t xq[BLOCK][4];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t p = blockIdx.x * per_block + grp;
+    bool live = grp < per_block && p < a.n;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq;
+    ProofCtx* c = live ? &a.ctxs[p] : nullptr;
+    const uint32_t* w = live ? reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]) : nullptr;
+    const uint32_t* ent = live ? a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G : nullptr;
+    const PlanHdr* h = live ? &a.pl.hdr[p] : nullptr;
+    uint32_t* leafv = live ? a.leafv + ((size_t)p * (3 + a.maxInner)) * G * 8 : nullptr;
+    const uint32_t gbase = grp * G;
+    uint32_t flags = 0;
+    uint32_t M = live ? m->M : 0, A = live ? m->A : 0, B = live ? m->B : 0;
+    uint32_t qj = live ? c->q[j] : 0;
+    uint32_t n_sizes = live ? c->n_sizes : 0;
+    QM31 first[3];
+    // ---- DEEP quotients + first-layer fold, per column log size
+    for (uint32_t g = 0; g < 3; g++) {
+        QM31 answer = q_zero();
+        uint32_t l = 0, pos = 0;
+        bool on = live && g < n_sizes;
+        if (on) {
+            l = c->sizes[g];
+            pos = qj >> (M - l);
+            QM31 r0 = q_zero(), r1 = q_zero();
+            uint32_t col = 0, dbl = 0;
+            const uint32_t ncols_group = (l == M) ? 8u : ((l == A ? 30u : 0u) + (l == B ? 96u : 0u));
+            for (int t = 0; t < 4; t++) {
+                if ((l == M) != (t == 3)) continue;
+                const uint32_t mx = (t == 3) ? M : umax(A, B);
+                const uint32_t nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+                const uint32_t* qv = w + m->qv_off[t];
+                const uint32_t qv_n = m->qv_n[t];
+                // the two components' columns of this tree at level l
+                for (int comp = 0; comp < 2; comp++) {
+                    uint32_t cl = (t == 3) ? M : (comp == 0 ? A : B);
+                    if (cl != l) continue;
+                    uint32_t nc = (t == 3) ? (comp == 0 ? 8u : 0u) : (comp == 0 ? plonk_cols(t) : poseidon_cols(t));
+                    if (nc == 0) continue;
+                    uint32_t off;
+                    if (cl == mx) off = ent_rb(ent[mx * G + j]) * nc_leaf + ((comp == 1 && A == B && t != 3) ? plonk_cols(t) : 0u);
+                    else off = lvl_nd(h->lvl[mx]) * nc_leaf + ent_rb(ent[cl * G + j]) * nc;
+                    bool inb = off + nc <= qv_n;
+                    if (!inb) flags |= 1u << (R_MERKLE_T0 + t);
+                    for (uint32_t k = 0; k < nc; k++) {
+                        uint32_t v = inb ? qv[off + k] : 0u;
+                        r0 = q_add(r0, q_mul_m(ldq(c->apow[col]), v));
+                        if (t == 2 && (k & 4)) {
+                            r1 = q_add(r1, q_mul_m(ldq(c->apow[ncols_group + dbl]), v));
+                            dbl++;
+                        }
+                        col++;
+                    }
+                }
+            }
+            CPoint dp = domain_point(l, pos);
+            for (uint32_t bi = 0; bi < c->n_batches[g]; bi++) {
+                const QBatch& qb = c->batch[g][bi];
+                CM31 prx = c_mk(qb.prx[0], qb.prx[1]), pix = c_mk(qb.pix[0], qb.pix[1]);
+                CM31 pry = c_mk(qb.pry[0], qb.pry[1]), piy = c_mk(qb.piy[0], qb.piy[1]);
+                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dp.y), ldq(qb.sb)));
+                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dp.x, 0)), piy), c_mul(c_sub(pry, c_mk(dp.y, 0)), pix));
+                answer = q_add(answer, q_mul_c(num, c_inv(den)));
+            }
+        }
+        // exchange answers: the pair sibling may be another query of this proof
+        stq(xq[threadIdx.x], answer);
+        __syncthreads();
+        if (on) {
+            uint32_t e = ent[l * G + j];
+            QM31 sib;
+            if (ent_sib(e) != 0xFFu) sib = ldq(xq[gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = c->fw_base[g] + ent_lb(e);
+                sib = wi < m->first.wit_n ? ldq(w + m->first.wit_off + 4 * wi) : q_zero();
+            }
+            uint32_t* lv = leafv + ((size_t)g * G + j) * 8;
+            stq(lv, answer); stq(lv + 4, sib);
+            // fold circle -> line with 1/y of the pair's base point (folding/src/lib.rs:57-90)
+            CPoint bp = domain_point(l, pos & ~1u);
+            first[g] = fold_pair(answer, sib, pos & 1u, m_inv(bp.y), ldq(c->fri_alpha[M - l]));
+        }
+        __syncthreads();
+    }
+    // ---- inner layers (folding/src/lib.rs:120-192)
+    QM31 folded = q_zero();
+    uint32_t l = M;
+    for (uint32_t i = 0; i < a.maxInner; i++) {
+        bool on = live && i < m->n_inner;
+        if (on) {
+            for (uint32_t g = 0; g < n_sizes; g++)
+                if (c->sizes[g] == l) {
+                    QM31 al = ldq(c->fri_alpha[i]);
+                    folded = q_add(q_mul(q_mul(al, al), folded), first[g]);
+                }
+            l -= 1;
+        }
+        stq(xq[threadIdx.x], folded);
+        __syncthreads();
+        if (on) {
+            uint32_t pos = qj >> (M - l);
+            uint32_t e = ent[l * G + j];
+            const FriLayerRef& L = m->inner[i];
+            QM31 sib;
+            if (ent_sib(e) != 0xFFu) sib = ldq(xq[gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = ent_lb(e);
+                sib = wi < L.wit_n ? ldq(w + L.wit_off + 4 * wi) : q_zero();
+            }
+            if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= 1u << R_FRI_INNER;  // hints/src/folding.rs:558
+            uint32_t* lv = leafv + ((size_t)(3 + i) * G + j) * 8;
+            stq(lv, folded); stq(lv + 4, sib);
+            uint32_t x = half_odds_at(l, bit_reverse(pos & ~1u, l)).x;
+            folded = fold_pair(folded, sib, pos & 1u, m_inv(x), ldq(c->fri_alpha[i + 1]));
+        }
+        __syncthreads();
+    }
+    // ---- last layer (folding/src/lib.rs:194-204, primitives/line/src/lib.rs:39-67)
+    if (live) {
+        uint32_t ll = l - 1, idx = (qj >> (M - l)) >> 1;
+        uint32_t x = half_odds_at(ll, bit_reverse(idx, ll)).x;
+        uint32_t log_n = m->log_last;
+        // fold(coeffs, [x, pi(x), ...]): evaluate bottom-up; coefficient i is
+        // weighted by prod_k d[k]^(bit (log_n-1-k) of i)
+        uint32_t d[16];
+        for (uint32_t k = 0; k < log_n; k++) { d[k] = x; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+        QM31 acc = q_zero();
+        const uint32_t* cf = w + m->last_off;
+#pragma unroll 1
+        for (uint32_t ci = 0; ci < m->last_n; ci++) {
+            uint32_t wgt = 1;
+            for (uint32_t k = 0; k < log_n; k++)
+                if ((ci >> (log_n - 1 - k)) & 1u) wgt = m_mul(wgt, d[k]);
+            acc = q_add(acc, q_mul_m(ldq(cf + 4 * ci), wgt));
+        }
+        if (!q_eq(acc, folded)) flags |= 1u << R_FRI_LAST;
+    }
+    if (flags) atomicOr(&c->flags, flags);
+}
+
+// ----------------------------------------------------------- k_trace_merkle
+// SinglePathMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:315-354)
+// for the four commitment trees: blockIdx.y = tree, one lane per (proof, query).
+struct MerkleArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n;
+    const ProofMeta* metas;
+    ProofCtx* ctxs;
+    PlanPtrs pl;
+    const uint32_t* leafv;
+    uint32_t maxInner;
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
+    __shared__ uint32_t xch[2][BLOCK][8];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t p = blockIdx.x * per_block + grp;
+    const int t = blockIdx.y;
+    bool live = grp < per_block && p < a.n;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq;
+    const uint32_t gbase = grp * G;
+    const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
+    uint32_t M = 0, A = 0, B = 0, mx = 0, nc_leaf = 0, qv_n = 0, hw_n = 0, s_top = 0, nd_leaf = 0;
+    const uint32_t *qv = nullptr, *hw = nullptr;
+    bool bad = false;
+    Hash8 cur = zero8();
+    uint32_t qj = 0;
+    if (live) {
+        w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+        ent = a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G;
+        h = &a.pl.hdr[p];
+        M = m->M; A = m->A; B = m->B;
+        mx = (t == 3) ? M : umax(A, B);
+        nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+        qv = w + m->qv_off[t]; qv_n = m->qv_n[t];
+        hw = w + m->hw_off[t]; hw_n = m->hw_n[t];
+        s_top = lvl_s(h->lvl[mx + 1]);
+        nd_leaf = lvl_nd(h->lvl[mx]);
+        qj = a.ctxs[p].q[j];
+        uint32_t off = ent_rb(ent[mx * G + j]) * nc_leaf;
+        if (off + nc_leaf > qv_n) bad = true;
+        else cur = leaf_from_capacity(sponge_capacity(qv + off, nc_leaf));
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl >= 1; lvl--) {  // child level
+        const uint32_t buf = lvl & 1u;
+        const bool on = live && lvl <= mx;
+        if (on) store_hash(xch[buf][threadIdx.x], cur);
+        __syncthreads();
+        if (on) {
+            uint32_t e = ent[lvl * G + j];
+            Hash8 sib;
+            if (ent_sib(e) != 0xFFu) sib = load_hash(xch[buf][gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
+                if (wi < hw_n) sib = load_hash(hw + 8 * wi);
+                else { sib = zero8(); bad = true; }
+            }
+            bool odd = (qj >> (M - lvl)) & 1u;
+            cur = odd ? hash_tree(sib, cur) : hash_tree(cur, sib);
+            const uint32_t pl_ = lvl - 1;  // parent level
+            uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));
+            if (nc) {
+                uint32_t off = nd_leaf * nc_leaf + ent_rb(ent[pl_ * G + j]) * nc;
+                if (off + nc > qv_n) bad = true;
+                else cur = combine_with_column(cur, sponge_capacity(qv + off, nc));
+            }
+        }
+    }
+    if (live) {
+        // every witness hash and queried value must be consumed (components/hints/src/decommit.rs:141-142)
+        uint32_t lower = (t == 3 || A == B) ? 0u : umin(A, B);
+        uint32_t nc_lower = (t == 3 || A == B) ? 0u : (lower == A ? plonk_cols(t) : poseidon_cols(t));
+        uint32_t want_qv = nd_leaf * nc_leaf + (lower ? lvl_nd(h->lvl[lower]) * nc_lower : 0u);
+        uint32_t want_hw = lvl_s(h->lvl[1]) - s_top;
+        bool ok = !bad && want_qv == qv_n && want_hw == hw_n && hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t));
+        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (R_MERKLE_T0 + t));
+    }
+}
+
+// ------------------------------------------------------------ k_pair_merkle
+// SinglePairMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:400-464):
+// blockIdx.y = 0 is the FRI first-layer tree (one QM31 column at each distinct
+// column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
+    __shared__ uint32_t xch[2][BLOCK][8];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t p = blockIdx.x * per_block + grp;
+    const uint32_t slot = blockIdx.y;
+    bool live = grp < per_block && p < a.n;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq && (slot == 0 || slot - 1 < m->n_inner);
+    const uint32_t gbase = grp * G;
+    const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
+    const uint32_t* fl = nullptr; const uint32_t* leafv = nullptr; const ProofCtx* c = nullptr;
+    const FriLayerRef* L = nullptr;
+    uint32_t M = 0, top = 0, qj = 0, s_top = 0, dslot = 0;
+    bool bad = false, have_sib = false;
+    Hash8 cur = zero8(), sibh = zero8();
+    if (live) {
+        w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+        ent = a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G;
+        fl = a.pl.fl + (size_t)p * 2 * G;
+        h = &a.pl.hdr[p];
+        c = &a.ctxs[p];
+        M = m->M;
+        L = slot == 0 ? &m->first : &m->inner[slot - 1];
+        top = slot == 0 ? M : M - slot;  // leaf level of this tree
+        qj = c->q[j];
+        s_top = lvl_s(h->lvl[top]);
+        leafv = a.leafv + ((size_t)p * (3 + a.maxInner)) * G * 8;
+        const uint32_t* lv = leafv + ((size_t)(slot == 0 ? 0 : 2 + slot) * G + j) * 8;
+        cur = leaf_from_capacity(sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
+        sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+        have_sib = true;
+        dslot = 0;
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl >= 1; lvl--) {  // child level
+        const bool on = live && lvl <= top;
+        const uint32_t pl_ = lvl - 1;
+        // is the parent level a data level of the first-layer tree?
+        int dg = -1;
+        if (on && slot == 0)
+            for (uint32_t g = 1; g < c->n_sizes; g++)
+                if (c->sizes[g] == pl_) dg = (int)g;
+        // phase A: sibling hash at the child level
+        if (on && !have_sib) store_hash(xch[0][threadIdx.x], cur);
+        __syncthreads();
+        if (on) {
+            if (!have_sib) {
+                uint32_t e = ent[lvl * G + j];
+                if (ent_sib(e) != 0xFFu) sibh = load_hash(xch[0][gbase + ent_sib(e)]);
+                else {
+                    uint32_t wi;
+                    if (slot == 0) wi = dg >= 0 ? (fl[dslot * G + j] & 0xFFFFu) : (uint32_t)h->wf[lvl] + ent_lb(e);
+                    else wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
+                    if (wi < L->hash_n) sibh = load_hash(w + L->hash_off + 8 * wi);
+                    else { sibh = zero8(); bad = true; }
+                }
+            }
+            bool odd = (qj >> (M - lvl)) & 1u;
+            cur = odd ? hash_tree(sibh, cur) : hash_tree(cur, sibh);
+            have_sib = false;
+        }
+        // phase B: data level of the first-layer tree: fold in the column and build the sibling node
+        if (on && dg >= 0) {
+            const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
+            cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
+            store_hash(xch[1][threadIdx.x], cur);
+        }
+        __syncthreads();
+        if (on && dg >= 0) {
+            const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
+            uint32_t w_sib = fl[dslot * G + j] >> 16;
+            if (w_sib == 0xFFFFu) {
+                uint32_t e = ent[pl_ * G + j];
+                if (ent_sib(e) != 0xFFu) sibh = load_hash(xch[1][gbase + ent_sib(e)]);
+                else bad = true;
+            } else if (w_sib + 1 < L->hash_n) {
+                Hash8 sn = hash_tree(load_hash(w + L->hash_off + 8 * w_sib), load_hash(w + L->hash_off + 8 * (w_sib + 1)));
+                sibh = combine_with_column(sn, sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+            } else bad = true;
+            have_sib = true;
+            dslot++;
+        }
+    }
+    if (live) {
+        uint32_t want_hw = slot == 0 ? (uint32_t)h->wf_total : lvl_s(h->lvl[1]) - s_top;
+        bool ok = !bad && want_hw == L->hash_n && hash_eq(cur, load_hash(w + L->commit_off));
+        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER));
+    }
+}
+
+// --------------------------------------------------------------- k_finalize
+__global__ __launch_bounds__(256) void k_finalize(uint32_t n, const ProofMeta* __restrict__ metas,
+                                                  const ProofCtx* __restrict__ ctxs, uint8_t* __restrict__ accept,
+                                                  uint8_t* __restrict__ reason) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t r = metas[p].reason;
+    if (r == R_OK) {
+        uint32_t f = ctxs[p].flags;
+        r = f ? (uint32_t)(__ffs((int)f) - 1) : R_OK;
+    }
+    accept[p] = r == R_OK;
+    if (reason) reason[p] = (uint8_t)r;
+}
+
+// accept bytes -> little-endian bitmap + popcount (the buffer the multi-GPU host all-gathers)
+__global__ __launch_bounds__(256) void k_bitmap(const uint8_t* __restrict__ accept, uint32_t n,
+                                                uint32_t* __restrict__ bitmap, unsigned long long* __restrict__ count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = i < n && accept[i];
+    unsigned long long mask = __ballot(bit);
+    uint32_t lane = threadIdx.x & 63;
+    if (lane == 0 && i < n) {
+        bitmap[i >> 5] = (uint32_t)mask;
+        if ((i >> 5) + 1 < (n + 31) / 32) bitmap[(i >> 5) + 1] = (uint32_t)(mask >> 32);
+        if (count && mask) atomicAdd(count, (unsigned long long)__popcll(mask));
+    }
+}
+
+}  // namespace rsv

@@ -1,0 +1,187 @@
+"""ctypes binding of the CPU oracle (oracle/librsv_oracle.so) — test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "librsv_oracle.so")
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class PcsConfig(ctypes.Structure):
+    _fields_ = [("pow_bits", ctypes.c_uint32), ("log_blowup_factor", ctypes.c_uint32),
+                ("log_last_layer_degree_bound", ctypes.c_uint32), ("n_queries", ctypes.c_uint32)]
+
+
+class PublicInput(ctypes.Structure):
+    _fields_ = [("idx", ctypes.c_uint32), ("value", ctypes.c_uint32 * 4)]
+
+
+def build():
+    src = os.path.join(ROOT, "oracle", "rsv_oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+build()
+lib = ctypes.CDLL(LIB)
+lib.rsvo_perm_count.restype = ctypes.c_uint64
+sz = ctypes.c_size_t
+lib.rsvo_poseidon2_permute.argtypes = [_u32p, _u32p, sz]
+lib.rsvo_poseidon2_half_permute.argtypes = [_u32p, _u32p, _u8p, _u32p, _u32p, sz]
+lib.rsvo_merkle_hash_node.argtypes = [_u32p, _u32p, _u32p, sz, _u32p, sz]
+lib.rsvo_merkle_path_root.argtypes = [_u32p, _u32p, _u32p, _u32p, ctypes.c_uint32, _u32p, sz]
+lib.rsvo_transcript.argtypes = [_u8p, sz, _u32p, sz]
+lib.rsvo_verify_batch.argtypes = [_u8p, _u64p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput), sz, _u8p, _u8p]
+lib.rsvo_query_values.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz]
+lib.rsvo_qm31_mul.argtypes = [_u32p, _u32p, _u32p]
+lib.rsvo_qm31_inv.argtypes = [_u32p, _u32p]
+lib.rsvo_domain_point.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _u32p]
+
+STANDARD_INPUTS = [(1, (1, 0, 0, 0)), (2, (0, 1, 0, 0)), (3, (0, 0, 1, 0))]
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def make_inputs(inputs):
+    items = list(inputs)
+    arr = (PublicInput * max(len(items), 1))()
+    for k, (idx, val) in enumerate(items):
+        arr[k].idx = idx
+        for t in range(4):
+            arr[k].value[t] = int(val[t])
+    return arr
+
+
+def poseidon2_permute(states):
+    s = _u32(states).reshape(-1, 16)
+    out = np.empty_like(s)
+    rc = lib.rsvo_poseidon2_permute(s.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), s.shape[0])
+    assert rc == 0, rc
+    return out
+
+
+def half_permute(left, right, swap=None):
+    l = _u32(left).reshape(-1, 8)
+    r = _u32(right).reshape(-1, 8)
+    n = l.shape[0]
+    sw = None if swap is None else np.ascontiguousarray(swap, dtype=np.uint8)
+    rate = np.empty((n, 8), np.uint32)
+    cap = np.empty((n, 8), np.uint32)
+    rc = lib.rsvo_poseidon2_half_permute(l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p),
+                                         None if sw is None else sw.ctypes.data_as(_u8p),
+                                         rate.ctypes.data_as(_u32p), cap.ctypes.data_as(_u32p), n)
+    assert rc == 0, rc
+    return rate, cap
+
+
+def hash_node(children, cols):
+    c = _u32(cols)
+    if c.ndim == 1:
+        c = c.reshape(1, -1)
+    n, n_cols = c.shape
+    out = np.empty((n, 8), np.uint32)
+    if children is None:
+        lp = rp = None
+    else:
+        l = _u32(children[0]).reshape(n, 8)
+        r = _u32(children[1]).reshape(n, 8)
+        lp, rp = l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p)
+    rc = lib.rsvo_merkle_hash_node(lp, rp, c.ctypes.data_as(_u32p) if n_cols else None, n_cols,
+                                   out.ctypes.data_as(_u32p), n)
+    assert rc == 0, rc
+    return out
+
+
+def merkle_path_root(query, siblings, cols, n_cols_at):
+    q = _u32(query).reshape(-1)
+    n = q.shape[0]
+    depth = len(n_cols_at) - 1
+    sib = _u32(siblings).reshape(n, depth, 8)
+    nca = _u32(n_cols_at)
+    c = _u32(cols).reshape(n, int(nca.sum()))
+    out = np.empty((n, 8), np.uint32)
+    rc = lib.rsvo_merkle_path_root(q.ctypes.data_as(_u32p), sib.ctypes.data_as(_u32p), c.ctypes.data_as(_u32p),
+                                   nca.ctypes.data_as(_u32p), depth, out.ctypes.data_as(_u32p), n)
+    assert rc == 0, rc
+    return out
+
+
+def transcript_raw(proof: bytes):
+    b = np.frombuffer(proof, dtype=np.uint8)
+    out = np.zeros(1024, np.uint32)
+    rc = lib.rsvo_transcript(b.ctypes.data_as(_u8p), len(proof), out.ctypes.data_as(_u32p), out.size)
+    assert rc == 0, rc
+    return out
+
+
+def pack(proofs):
+    offsets = np.zeros(len(proofs) + 1, np.uint64)
+    if proofs:
+        offsets[1:] = np.cumsum([len(p) for p in proofs], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(proofs), dtype=np.uint8) if proofs else np.zeros(0, np.uint8)
+    return blob, offsets
+
+
+def verify_batch(proofs, inputs=STANDARD_INPUTS, cfg=None):
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    rc = lib.rsvo_verify_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n,
+                               ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+                               accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_verify_batch -> {rc}")
+    return accept, reason
+
+
+def perm_count(proof: bytes, inputs=STANDARD_INPUTS):
+    lib.rsvo_perm_count_reset()
+    verify_batch([proof], inputs)
+    return int(lib.rsvo_perm_count())
+
+
+def qm31_mul(a, b):
+    a, b = _u32(a), _u32(b)
+    out = np.zeros(4, np.uint32)
+    lib.rsvo_qm31_mul(a.ctypes.data_as(_u32p), b.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p))
+    return out
+
+
+def qm31_inv(a):
+    a = _u32(a)
+    out = np.zeros(4, np.uint32)
+    lib.rsvo_qm31_inv(a.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p))
+    return out
+
+
+def domain_point(log_size, q):
+    out = np.zeros(2, np.uint32)
+    lib.rsvo_domain_point(log_size, q, out.ctypes.data_as(_u32p))
+    return int(out[0]), int(out[1])
+
+
+def splitmix64(seed, i):
+    """splitmix64 stream used for seeded tampering."""
+    mask = (1 << 64) - 1
+    z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & mask
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+    return z ^ (z >> 31)
+
+
+def tamper(proof: bytes, i: int, seed: int = 0xC0FFEE) -> bytes:
+    """Flip the low bit of one byte at offset 60 + splitmix64(seed, i) % (len - 68)."""
+    b = bytearray(proof)
+    off = 60 + splitmix64(seed, i) % (len(b) - 68)
+    b[off] ^= 1
+    return bytes(b)

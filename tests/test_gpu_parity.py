@@ -1,0 +1,208 @@
+"""GPU parity tests: every C-ABI entry point of librsv_hip.so against the CPU oracle on the same
+inputs (bit-exact: all arithmetic is integer), and against the committed golden fixtures."""
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+from tests.conftest import load_manifest, read_proof
+
+pytestmark = pytest.mark.gpu
+P = 0x7FFFFFFF
+KAT_OUT = [260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083, 755063943,
+           1682438524, 1265420601, 238640995, 200799880, 1659717477, 2080202267, 1269806256, 1287849264]
+
+
+def entry_inputs(e):
+    return [(i, tuple(v)) for i, v in e["inputs"]]
+
+
+def test_device_present(rsv):
+    assert rsv.device_count() >= 1
+
+
+def test_poseidon2_kat(rsv):
+    assert rsv.poseidon2_permute(np.arange(16, dtype=np.uint32))[0].tolist() == KAT_OUT
+
+
+def test_poseidon2_random_states(rsv):
+    rng = np.random.default_rng(1)
+    n = 1 << 15
+    s = rng.integers(0, P, (n, 16), dtype=np.uint32)
+    s[0] = 0
+    s[1] = P - 1
+    assert np.array_equal(rsv.poseidon2_permute(s), ob.poseidon2_permute(s))
+
+
+def test_poseidon2_ragged_sizes(rsv):
+    rng = np.random.default_rng(2)
+    for n in (1, 63, 64, 65, 255, 257, 1000):
+        s = rng.integers(0, P, (n, 16), dtype=np.uint32)
+        assert np.array_equal(rsv.poseidon2_permute(s), ob.poseidon2_permute(s))
+    assert rsv.poseidon2_permute(np.zeros((0, 16), np.uint32)).shape == (0, 16)
+
+
+def test_poseidon2_rejects_noncanonical(rsv):
+    s = np.zeros((4, 16), np.uint32)
+    s[2, 5] = P
+    with pytest.raises(rsv.RsvError) as e:
+        rsv.poseidon2_permute(s)
+    assert e.value.code == -5
+
+
+def test_half_permute(rsv):
+    rng = np.random.default_rng(3)
+    n = 1000
+    l = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    r = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    sw = rng.integers(0, 2, n, dtype=np.uint8)
+    for swap in (None, sw):
+        rate, cap = rsv.half_permute(l, r, swap)
+        orate, ocap = ob.half_permute(l, r, swap)
+        assert np.array_equal(rate, orate) and np.array_equal(cap, ocap)
+
+
+@pytest.mark.parametrize("n_cols", [0, 1, 4, 7, 8, 13, 16, 17, 21, 25, 48])
+def test_hash_node(rsv, n_cols):
+    # column lengths 7/13/16/17/21/25 are the ones primitives/merkle/src/lib.rs:207-303 tests
+    rng = np.random.default_rng(n_cols)
+    n = 300
+    cols = rng.integers(0, P, (n, n_cols), dtype=np.uint32)
+    l = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    r = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    assert np.array_equal(rsv.hash_node((l, r), cols), ob.hash_node((l, r), cols))
+    if n_cols:
+        assert np.array_equal(rsv.hash_node(None, cols), ob.hash_node(None, cols))
+
+
+def test_hash_node_checkpoints(rsv):
+    assert rsv.hash_node(None, [1, 2, 3, 4, 5])[0].tolist() == [
+        557709851, 1113733662, 222169927, 1376019790, 387901840, 1087892516, 628125718, 969660801]
+
+
+def test_merkle_path_root(rsv):
+    rng = np.random.default_rng(5)
+    depth = 13
+    n_cols_at = [0] * (depth + 1)
+    n_cols_at[depth] = 40
+    n_cols_at[9] = 10
+    n_cols_at[4] = 3
+    n = 200
+    q = rng.integers(0, 1 << depth, n, dtype=np.uint32)
+    sib = rng.integers(0, P, (n, depth, 8), dtype=np.uint32)
+    cols = rng.integers(0, P, (n, sum(n_cols_at)), dtype=np.uint32)
+    assert np.array_equal(rsv.merkle_path_root(q, sib, cols, n_cols_at), ob.merkle_path_root(q, sib, cols, n_cols_at))
+
+
+@pytest.mark.parametrize("entry", load_manifest(), ids=lambda e: e["file"])
+def test_transcript_matches_oracle(rsv, entry):
+    proof = read_proof(entry["file"])
+    want = rsv._parse_transcript(ob.transcript_raw(proof))
+    got = rsv.transcript(proof)
+    assert got == want
+
+
+def test_all_fixtures_one_mixed_batch(rsv, manifest):
+    std = [e for e in manifest if len(e["inputs"]) == 3]
+    proofs = [read_proof(e["file"]) for e in std]
+    acc, reason = rsv.verify_batch(proofs)
+    oacc, oreason = ob.verify_batch(proofs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    for e, a in zip(std, acc):
+        assert bool(a) == (e["expect"] == "ok"), e["file"]
+
+
+@pytest.mark.parametrize("entry", load_manifest(), ids=lambda e: e["file"])
+def test_fixture_verdict(rsv, entry):
+    proof = read_proof(entry["file"])
+    cfg = rsv.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
+                        entry["n_queries"])
+    acc, reason = rsv.verify_batch([proof], entry_inputs(entry), cfg)
+    assert bool(acc[0]) == (entry["expect"] == "ok")
+    ocfg = ob.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
+                        entry["n_queries"])
+    oacc, oreason = ob.verify_batch([proof], entry_inputs(entry), ocfg)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+
+
+@pytest.mark.parametrize("name,n_tamper", [("small_proof.bin", 96), ("recursive_proof_16_15.bin", 64),
+                                           ("level13-1.bin", 32), ("level2-1.bin", 16), ("level1-5.bin", 8)])
+def test_tampered_proofs_match_oracle(rsv, manifest, name, n_tamper):
+    entry = next(e for e in manifest if e["file"] == name)
+    proof = read_proof(name)
+    batch = [ob.tamper(proof, i) for i in range(n_tamper)] + [proof]
+    acc, reason = rsv.verify_batch(batch, entry_inputs(entry))
+    oacc, oreason = ob.verify_batch(batch, entry_inputs(entry))
+    assert acc.tolist() == oacc.tolist()
+    assert reason.tolist() == oreason.tolist()
+    assert acc[-1] == 1 and acc[:-1].sum() == 0
+
+
+def test_wrong_inputs_and_config(rsv):
+    proof = read_proof("small_proof.bin")
+    acc, reason = rsv.verify_batch([proof], [(1, (2, 0, 0, 0))])
+    assert (acc[0], reason[0]) == (0, 3)
+    acc, reason = rsv.verify_batch([proof], [(1, (1, 0, 0, 0))], rsv.PcsConfig(20, 5, 2, 15))
+    assert (acc[0], reason[0]) == (0, 1)
+    with pytest.raises(rsv.RsvError) as e:
+        rsv.verify_batch([proof], [(1, (P, 0, 0, 0))])
+    assert e.value.code == -5
+
+
+def test_truncated_garbage_and_empty(rsv):
+    proof = read_proof("small_proof.bin")
+    rng = np.random.default_rng(7)
+    batch = [proof[:cut] for cut in (0, 4, 60, 3580, len(proof) - 4)] + [proof + b"\0\0\0\0"]
+    batch += [rng.integers(0, 256, 4096, dtype=np.uint8).tobytes(), proof]
+    acc, reason = rsv.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    oacc, oreason = ob.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    assert acc.tolist() == oacc.tolist() == [0] * 7 + [1]
+    assert reason.tolist() == oreason.tolist()
+    acc, _ = rsv.verify_batch([], [(1, (1, 0, 0, 0))])
+    assert len(acc) == 0
+
+
+def test_config2_batch_1024_copies(rsv):
+    """BASELINE config 2: 1 024 copies of recursive_proof_16_15.bin with the seeded tamper rule of
+    SURVEY §8d (proof i with i % 17 == 5 gets one flipped bit); verdicts bit-exact vs the oracle."""
+    proof = read_proof("recursive_proof_16_15.bin")
+    batch = [ob.tamper(proof, i) if i % 17 == 5 else proof for i in range(1024)]
+    acc, reason = rsv.verify_batch(batch)
+    # the oracle only needs to judge the distinct inputs
+    tampered = [i for i in range(1024) if i % 17 == 5]
+    oacc, oreason = ob.verify_batch([batch[i] for i in tampered] + [proof])
+    want_acc = np.full(1024, oacc[-1], np.uint8)
+    want_reason = np.full(1024, oreason[-1], np.uint8)
+    want_acc[tampered] = oacc[:-1]
+    want_reason[tampered] = oreason[:-1]
+    assert acc.tolist() == want_acc.tolist()
+    assert reason.tolist() == want_reason.tolist()
+    assert int(acc.sum()) == 1024 - len(tampered)
+
+
+def test_device_resident_api_and_bitmap(rsv):
+    import torch
+    proof = read_proof("recursive_proof_16_15.bin")
+    n = 300
+    batch = [ob.tamper(proof, i) if i % 7 == 3 else proof for i in range(n)]
+    blob, offsets = rsv.pack(batch)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctx = rsv.Context(0)
+    for _ in range(2):  # second call reuses the workspace
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason)
+    ctx.accept_bitmap(d_acc, n, d_bitmap, d_count)
+    ctx.synchronize()
+    acc = d_acc.cpu().numpy()
+    want = np.array([0 if i % 7 == 3 else 1 for i in range(n)], np.uint8)
+    assert acc.tolist() == want.tolist()
+    bits = np.unpackbits(d_bitmap.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+    assert bits.tolist() == want.tolist()
+    assert int(d_count.item()) == int(want.sum())
+    times = ctx.last_stage_times()
+    assert set(times) >= {"trace_merkle", "pair_merkle", "transcript"} and all(v >= 0 for v in times.values())
+    ctx.close()

@@ -1,0 +1,160 @@
+"""CPU tests of the oracle against the reference's own known answers:
+the literal Poseidon2 KAT, the hasher/channel/transcript checkpoints of SURVEY App. C and the
+accept/reject behaviour of every proof fixture under the config written in the reference source."""
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+from tests.conftest import load_manifest, read_proof
+
+P = 0x7FFFFFFF
+
+# primitives/poseidon31/src/implementation.rs:157-172
+KAT_OUT = [260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083, 755063943,
+           1682438524, 1265420601, 238640995, 200799880, 1659717477, 2080202267, 1269806256, 1287849264]
+
+
+def test_poseidon2_kat():
+    out = ob.poseidon2_permute(np.arange(16, dtype=np.uint32))
+    assert out[0].tolist() == KAT_OUT
+
+
+def test_poseidon2_rejects_noncanonical():
+    s = np.zeros(16, np.uint32)
+    s[3] = P
+    out = np.zeros(16, np.uint32)
+    rc = ob.lib.rsvo_poseidon2_permute(s.ctypes.data_as(ob._u32p), out.ctypes.data_as(ob._u32p), 1)
+    assert rc == -5
+
+
+def test_hash_node_checkpoints():
+    # SURVEY App. C
+    assert ob.hash_node(None, [1, 2, 3, 4, 5])[0].tolist() == [
+        557709851, 1113733662, 222169927, 1376019790, 387901840, 1087892516, 628125718, 969660801]
+    l, r = np.arange(1, 9), np.arange(9, 17)
+    assert ob.hash_node((l, r), np.zeros((1, 0)))[0].tolist() == [
+        164793487, 387042994, 621688597, 428853092, 1214488792, 1623406829, 1918424220, 1537261691]
+    assert ob.hash_node((l, r), [7, 7, 7])[0].tolist() == [
+        2077916493, 57586551, 1709117860, 800174306, 352135528, 1590574078, 1798659285, 1176940757]
+
+
+def test_half_permute_swap_semantics():
+    # primitives/poseidon31/src/lib.rs:293-309: swap => state = right || left
+    rng = np.random.default_rng(1)
+    l = rng.integers(0, P, (4, 8), dtype=np.uint32)
+    r = rng.integers(0, P, (4, 8), dtype=np.uint32)
+    rate, cap = ob.half_permute(l, r, [0, 1, 0, 1])
+    full = ob.poseidon2_permute(np.concatenate([l, r], axis=1))
+    full_sw = ob.poseidon2_permute(np.concatenate([r, l], axis=1))
+    for i, sw in enumerate([0, 1, 0, 1]):
+        want = full_sw[i] if sw else full[i]
+        assert rate[i].tolist() == want[:8].tolist() and cap[i].tolist() == want[8:].tolist()
+
+
+def test_sponge_matches_manual_chain():
+    # primitives/merkle/src/lib.rs:141-181 for the column lengths the reference tests (7/13/16/17/21/25)
+    rng = np.random.default_rng(0)
+    for n in (7, 13, 16, 17, 21, 25):
+        cols = rng.integers(0, P, n, dtype=np.uint32)
+        d = np.zeros(8, np.uint32)
+        for off in range(0, n, 8):
+            chunk = np.zeros(8, np.uint32)
+            k = min(8, n - off)
+            chunk[:k] = cols[off:off + k]
+            d = ob.poseidon2_permute(np.concatenate([chunk, d]))[0][8:]
+        leaf = ob.poseidon2_permute(np.concatenate([np.zeros(8, np.uint32), d]))[0][:8]
+        assert ob.hash_node(None, cols)[0].tolist() == leaf.tolist()
+
+
+def test_small_proof_transcript_checkpoints():
+    out = ob.transcript_raw(read_proof("small_proof.bin"))
+    assert out[0] == 0 and out[1] == 8 and out[2] == 16 and out[3] == 15
+    assert out[4:8].tolist() == [1211683141, 437669427, 409200369, 1127771350]       # z
+    assert out[8:12].tolist() == [608237629, 60905622, 1129253272, 1937554417]        # alpha
+    assert out[12:16].tolist() == [510535785, 709795745, 2021304333, 468388088]       # random_coeff
+    assert out[16:20].tolist() == [432538781, 1881392761, 1838851372, 291147612]      # oods t
+    assert out[28:32].tolist() == [258757294, 1276317760, 1536227746, 6873968]        # after sampled values
+    assert out[40:44].tolist() == [2118644044, 1562770230, 410003546, 1078681992]     # fri_alpha[0]
+    assert out[68:72].tolist() == [1686932136, 243723819, 74374586, 128365204]        # fri_alpha[7]
+    q = out[72:88] & ((1 << 15) - 1)
+    assert q.tolist() == [3311, 10908, 19594, 28340, 20569, 32639, 20328, 27419, 4097, 16595, 24642, 2474,
+                          29786, 20017, 13022, 23721]
+
+
+@pytest.mark.parametrize("entry", load_manifest(), ids=lambda e: e["file"])
+def test_fixture_verdict(entry):
+    proof = read_proof(entry["file"])
+    inputs = [(i, tuple(v)) for i, v in entry["inputs"]]
+    cfg = ob.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
+                       entry["n_queries"])
+    acc, reason = ob.verify_batch([proof], inputs, cfg)
+    if entry["expect"] == "ok":
+        assert acc[0] == 1 and reason[0] == 0
+        acc2, _ = ob.verify_batch([proof], inputs, None)
+        assert acc2[0] == 1
+    else:
+        assert acc[0] == 0 and reason[0] != 0
+
+
+def test_permutation_counts():
+    # SURVEY App. C (transcript + batched Merkle); the survey's transcript figure includes
+    # ceil(n_q/4) query draws where ceil(n_q/8) suffice, hence the small constant offsets.
+    assert ob.perm_count(read_proof("recursive_proof_16_15.bin")) == 233 + 4230 - 2
+    assert ob.perm_count(read_proof("small_proof.bin"), [(1, (1, 0, 0, 0))]) == 105 + 2736 - 2
+
+
+def test_wrong_config_rejected():
+    proof = read_proof("small_proof.bin")
+    cfg = ob.PcsConfig(20, 5, 2, 15)
+    acc, reason = ob.verify_batch([proof], [(1, (1, 0, 0, 0))], cfg)
+    assert acc[0] == 0 and reason[0] == 1
+
+
+def test_wrong_public_input_rejected():
+    proof = read_proof("small_proof.bin")
+    acc, reason = ob.verify_batch([proof], [(1, (2, 0, 0, 0))])
+    assert acc[0] == 0 and reason[0] == 3  # logup
+    acc, reason = ob.verify_batch([read_proof("recursive_proof_16_15.bin")], [(1, (1, 0, 0, 0))])
+    assert acc[0] == 0 and reason[0] == 3
+
+
+def test_tampered_proofs_rejected():
+    proof = read_proof("small_proof.bin")
+    bad = [ob.tamper(proof, i) for i in range(40)]
+    acc, reason = ob.verify_batch(bad, [(1, (1, 0, 0, 0))])
+    assert acc.sum() == 0
+    assert set(reason.tolist()) <= set(range(1, 13))
+    # several different stages must be hit (pow, trees, FRI first/inner, parse)
+    assert len(set(reason.tolist())) >= 4
+
+
+def test_truncated_and_empty():
+    proof = read_proof("small_proof.bin")
+    for cut in (0, 4, 60, 3580, len(proof) - 4):
+        acc, reason = ob.verify_batch([proof[:cut]], [(1, (1, 0, 0, 0))])
+        assert acc[0] == 0 and reason[0] == 1
+    acc, reason = ob.verify_batch([proof + b"\0\0\0\0"], [(1, (1, 0, 0, 0))])
+    assert acc[0] == 0 and reason[0] == 1
+    acc, _ = ob.verify_batch([], [(1, (1, 0, 0, 0))])
+    assert len(acc) == 0
+
+
+def test_qm31_field_identities():
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        a = rng.integers(1, P, 4, dtype=np.uint32)
+        assert ob.qm31_mul(a, ob.qm31_inv(a)).tolist() == [1, 0, 0, 0]
+    # u^2 = 2 + i  
+    assert ob.qm31_mul([0, 0, 1, 0], [0, 0, 1, 0]).tolist() == [2, 1, 0, 0]
+    assert ob.qm31_mul([0, 1, 0, 0], [0, 1, 0, 0]).tolist() == [P - 1, 0, 0, 0]
+
+
+def test_domain_points_on_circle():
+    for log in (5, 13, 22):
+        for q in (0, 1, 2, (1 << log) - 1):
+            x, y = ob.domain_point(log, q)
+            assert (x * x + y * y) % P == 1
+        # bit 0 of the query selects the conjugate (primitives/query/src/lib.rs:139-143)
+        x0, y0 = ob.domain_point(log, 6)
+        x1, y1 = ob.domain_point(log, 7)
+        assert x0 == x1 and (y0 + y1) % P == 0
