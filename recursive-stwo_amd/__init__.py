@@ -53,6 +53,12 @@ class PublicInput(ctypes.Structure):
 
 
 def _load() -> ctypes.CDLL:
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  Import torch first so that
+    # the process holds ONE runtime and the tensors torch allocates are visible to this library's stream.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
