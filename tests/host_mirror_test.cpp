@@ -1,0 +1,123 @@
+// host_mirror_test.cpp — the reference's own unit tests, restated against the C++ host mirror
+// (recursive-stwo_amd/host/recursive_stwo.hpp).  Runs on the GPU box (tests/test_host_mirror.py).
+//   test_poseidon2_permute      primitives/poseidon31/src/implementation.rs:157-172
+//   test_consistency (merkle)   primitives/merkle/src/lib.rs:206-303 (expected values: SURVEY App. C)
+//   test_fiat_shamir            components/recursive/fiat_shamir/src/lib.rs:197-236 (challenges: SURVEY App. C)
+//   test_folding (= full verify) components/recursive/folding/src/lib.rs:231-303
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+#include "../recursive-stwo_amd/host/recursive_stwo.hpp"
+
+using namespace recursive_stwo;
+
+#define EXPECT(cond)                                                          \
+    do {                                                                      \
+        if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } \
+    } while (0)
+
+static std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    EXPECT(f.good());
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static void test_poseidon2_permute() {
+    std::array<M31, 16> state{};
+    for (uint32_t i = 0; i < 16; i++) state[i] = i;
+    poseidon31::poseidon2_permute(state);
+    const std::array<M31, 16> want = {260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083,
+                                      755063943, 1682438524, 1265420601, 238640995, 200799880, 1659717477, 2080202267,
+                                      1269806256, 1287849264};
+    EXPECT(state == want);
+}
+
+static void test_merkle_consistency() {
+    // hash_m31_columns_get_rate == Poseidon31MerkleHasher::hash_node(None, cols)
+    for (size_t len : {7u, 13u, 16u, 17u, 21u, 25u}) {
+        std::vector<M31> cols(len);
+        for (size_t i = 0; i < len; i++) cols[i] = (uint32_t)(1000003u * (i + 1) + len) % RSV_M31_P;
+        HashVar a = Poseidon31MerkleHasherVar::hash_m31_columns_get_rate(cols);
+        HashVar b = HashVar::permute_get_rate(HashVar::zero(), Poseidon31MerkleHasherVar::hash_m31_columns_get_capacity(cols));
+        EXPECT(a.value == b.value);
+    }
+    EXPECT((Poseidon31MerkleHasherVar::hash_m31_columns_get_rate({1, 2, 3, 4, 5}).value ==
+            Hash{557709851, 1113733662, 222169927, 1376019790, 387901840, 1087892516, 628125718, 969660801}));
+    M31 l8[8] = {1, 2, 3, 4, 5, 6, 7, 8}, r8[8] = {9, 10, 11, 12, 13, 14, 15, 16};
+    HashVar l = HashVar::from_m31(l8), r = HashVar::from_m31(r8);
+    EXPECT((Poseidon31MerkleHasherVar::hash_tree(l, r).value ==
+            Hash{164793487, 387042994, 621688597, 428853092, 1214488792, 1623406829, 1918424220, 1537261691}));
+    HashVar col = Poseidon31MerkleHasherVar::hash_m31_columns_get_capacity({7, 7, 7});
+    EXPECT((Poseidon31MerkleHasherVar::hash_tree_with_column(l, r, col).value ==
+            Hash{2077916493, 57586551, 1709117860, 800174306, 352135528, 1590574078, 1798659285, 1176940757}));
+    // swap variants: primitives/merkle/src/lib.rs:22-41
+    EXPECT(Poseidon31MerkleHasherVar::hash_tree_with_swap(l, r, true).value == Poseidon31MerkleHasherVar::hash_tree(r, l).value);
+}
+
+static void test_channel(const std::vector<uint8_t>& small) {
+    // commitment[0] of small_proof.bin lives at byte 68; digest after mix_root: SURVEY App. C
+    HashVar c0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t w;
+        memcpy(&w, small.data() + 68 + 4 * i, 4);
+        c0.value[i] = w;
+    }
+    EXPECT((c0.value == Hash{408034276, 2096354985, 1338871816, 1690865784, 2073546231, 904203018, 917926113, 1884771894}));
+    ChannelVar channel;
+    channel.mix_root(c0);
+    EXPECT((channel.digest.value == Hash{1662218662, 1343911353, 1635652531, 1581605795, 624037075, 24422224, 442561826, 420390772}));
+    EXPECT(channel.n_sent == 0);
+    auto d0 = channel.draw_felts();
+    auto d1 = channel.draw_felts();
+    EXPECT(channel.n_sent == 2 && d0 != d1);
+}
+
+static void test_fiat_shamir(const std::vector<uint8_t>& small) {
+    FiatShamirResults r = FiatShamirResults::compute(small);
+    EXPECT((r.z == QM31{1211683141, 437669427, 409200369, 1127771350}));
+    EXPECT((r.alpha == QM31{608237629, 60905622, 1129253272, 1937554417}));
+    EXPECT((r.random_coeff == QM31{510535785, 709795745, 2021304333, 468388088}));
+    EXPECT((r.oods_t == QM31{432538781, 1881392761, 1838851372, 291147612}));
+    EXPECT((r.after_sampled_values_random_coeff == QM31{258757294, 1276317760, 1536227746, 6873968}));
+    EXPECT(r.fri_alphas.size() == 8);
+    EXPECT((r.fri_alphas[0] == QM31{2118644044, 1562770230, 410003546, 1078681992}));
+    EXPECT((r.fri_alphas[7] == QM31{1686932136, 243723819, 74374586, 128365204}));
+    EXPECT(r.raw_queries.size() == 16 && r.max_first_layer_column_log_size == 15);
+    EXPECT((r.raw_queries[0] & 0x7fff) == 3311 && (r.raw_queries[15] & 0x7fff) == 23721);
+}
+
+static void test_verify(const std::vector<uint8_t>& small) {
+    PcsConfig config{20, FriConfig::make(2, 5, 16)};
+    Inputs inputs = {{1, QM31{1, 0, 0, 0}}};
+    Verifier::verify(small, config, inputs);  // must not throw
+    bool threw = false;
+    try {
+        Verifier::verify(small, PcsConfig{20, FriConfig::make(2, 5, 15)}, inputs);
+    } catch (const VerificationError& e) { threw = e.reason == RSV_R_PARSE; }
+    EXPECT(threw);
+    threw = false;
+    try {
+        Verifier::verify(small, config, {{1, QM31{2, 0, 0, 0}}});
+    } catch (const VerificationError& e) { threw = e.reason == RSV_R_LOGUP; }
+    EXPECT(threw);
+    auto bad = small;
+    bad[30000] ^= 1;
+    std::vector<uint8_t> acc, reason;
+    Verifier::verify_batch({small, bad}, config, inputs, acc, reason);
+    EXPECT(acc[0] == 1 && acc[1] == 0 && reason[1] != 0);
+}
+
+int main(int argc, char** argv) {
+    std::string dir = argc > 1 ? argv[1] : "tests/golden/proofs";
+    auto small = read_file(dir + "/small_proof.bin");
+    test_poseidon2_permute();
+    test_merkle_consistency();
+    test_channel(small);
+    test_fiat_shamir(small);
+    test_verify(small);
+    printf("host mirror: all tests passed\n");
+    return 0;
+}

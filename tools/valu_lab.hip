@@ -1,0 +1,118 @@
+// valu_lab.hip — instruction-throughput microbenchmarks for the integer VALU ops the Poseidon2
+// permutation is made of (MI355X / gfx950).  Build: hipcc --offload-arch=gfx950 -O3 -o valu_lab valu_lab.hip
+// Prints wave-instruction issue cycles per SIMD assuming every SIMD holds WAVES waves.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define ITERS 65536
+#define CHAINS 8
+
+#define DEF_KERNEL(NAME, ASM_LINE)                                                                   \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {                      \
+        uint32_t a[CHAINS];                                                                          \
+        uint32_t b = seed | 1u, c = seed + 12345u;                                                   \
+        uint64_t w[CHAINS];                                                                          \
+        for (int i = 0; i < CHAINS; i++) { a[i] = threadIdx.x * 2654435761u + i + seed; w[i] = a[i]; } \
+        for (int it = 0; it < ITERS; it++) {                                                         \
+            _Pragma("unroll") for (int i = 0; i < CHAINS; i++) { ASM_LINE; }                         \
+        }                                                                                            \
+        uint32_t r = 0;                                                                              \
+        for (int i = 0; i < CHAINS; i++) r ^= a[i] ^ (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);         \
+        if (r == 0x12345678u) out[0] = r;                                                            \
+    }
+
+DEF_KERNEL(k_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_add3, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_min, asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_and, asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_and_or, asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_lshl_add, asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mul_lo, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mul_hi, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mul_u24, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mad_u24, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_mad64, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, 0" : "=v"(w[i]) : "v"(a[i]), "v"(b) : "s10", "s11"))
+DEF_KERNEL(k_mad64_acc, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b) : "s10", "s11"))
+DEF_KERNEL(k_lshl_add64, asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS])))
+DEF_KERNEL(k_lshl_add64_0, asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS])))
+DEF_KERNEL(k_lshl64, asm volatile("v_lshlrev_b64 %0, 5, %0" : "+v"(w[i])))
+DEF_KERNEL(k_add_co, asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc"))
+DEF_KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20","s21"))
+DEF_KERNEL(k_bfe, asm volatile("v_bfe_u32 %0, %0, 3, 15" : "+v"(a[i])))
+DEF_KERNEL(k_pk_add16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_fma32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_fma64, asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS])))
+DEF_KERNEL(k_mul_i32_i24, asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+
+
+DEF_KERNEL(k_sub, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_or, asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_xor, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_lshl, asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i])))
+DEF_KERNEL(k_lshr, asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i])))
+DEF_KERNEL(k_max, asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mini, asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mov, asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_xad, asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_add_lshl, asm volatile("v_add_lshl_u32 %0, %0, %1, 1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_med3, asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_min3, asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_cmp_cnd, asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"))
+DEF_KERNEL(k_sub_co_cnd, asm volatile("v_sub_co_u32 %2, vcc, %0, %1\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"))
+DEF_KERNEL(k_addc, asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"))
+DEF_KERNEL(k_add_s, asm volatile("v_add_u32 %0, s20, %0" : "+v"(a[i]) : : "s20"))
+DEF_KERNEL(k_add_lit, asm volatile("v_add_u32 %0, 0x80000001, %0" : "+v"(a[i])))
+DEF_KERNEL(k_and_lit, asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(a[i])))
+DEF_KERNEL(k_min_lit, asm volatile("v_min_u32 %0, 0x7fffffff, %0" : "+v"(a[i])))
+DEF_KERNEL(k_mad64_s, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, s20, %0" : "+v"(w[i]) : "v"(a[i]) : "s10", "s11", "s20"))
+DEF_KERNEL(k_mul_lo_2dep, asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(a[i])))
+DEF_KERNEL(k_sub_nc, asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_ashr, asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i])))
+DEF_KERNEL(k_dot, asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+
+typedef void (*kern_t)(uint32_t*, uint32_t);
+struct Case { const char* name; kern_t k; };
+
+int main(int argc, char** argv) {
+    int waves_per_simd = argc > 1 ? atoi(argv[1]) : 4;
+    uint32_t* out;
+    hipMalloc(&out, 4096);
+    Case cases[] = {{"v_add_u32", k_add}, {"v_add3_u32", k_add3}, {"v_min_u32", k_min}, {"v_and_b32", k_and},
+                    {"v_alignbit_b32", k_alignbit}, {"v_and_or_b32", k_and_or}, {"v_lshl_add_u32", k_lshl_add},
+                    {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi}, {"v_mul_u32_u24", k_mul_u24},
+                    {"v_mad_u32_u24", k_mad_u24}, {"v_mul_hi_u32_u24", k_mul_i32_i24},
+                    {"v_mad_u64_u32(0)", k_mad64}, {"v_mad_u64_u32(acc)", k_mad64_acc},
+                    {"v_lshl_add_u64<<1", k_lshl_add64}, {"v_lshl_add_u64<<0", k_lshl_add64_0}, {"v_lshlrev_b64", k_lshl64},
+                    {"v_add_co_u32", k_add_co}, {"v_cndmask_b32", k_cndmask}, {"v_bfe_u32", k_bfe},
+                    {"v_pk_add_u16", k_pk_add16}, {"v_fma_f32", k_fma32}, {"v_fma_f64", k_fma64},
+                    {"v_sub_u32", k_sub}, {"v_subrev_u32", k_sub_nc}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshlrev_b32", k_lshl}, {"v_lshrrev_b32", k_lshr},
+                    {"v_ashrrev_i32", k_ashr}, {"v_max_u32", k_max}, {"v_min_i32", k_mini}, {"v_mov_b32", k_mov}, {"v_bfi_b32", k_bfi}, {"v_xad_u32", k_xad},
+                    {"v_add_lshl_u32", k_add_lshl}, {"v_med3_u32", k_med3}, {"v_min3_u32", k_min3}, {"cmp+cndmask (2)", k_cmp_cnd},
+                    {"sub_co+cndmask (2)", k_sub_co_cnd}, {"v_addc_co_u32", k_addc}, {"v_add_u32 sgpr", k_add_s}, {"v_add_u32 literal", k_add_lit},
+                    {"v_and_b32 literal", k_and_lit}, {"v_min_u32 literal", k_min_lit}, {"v_mad_u64_u32 sgpr", k_mad64_s}, {"v_mul_lo self", k_mul_lo_2dep}, {"v_mad_i32_i24", k_dot}};
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    int cus = prop.multiProcessorCount;
+    int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+    printf("CUs %d, clock %d kHz, %d waves/SIMD\n", cus, prop.clockRate, waves_per_simd);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (auto& c : cases) {
+        hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1u);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; r++) hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1u + r);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double insts_per_simd = 5.0 * waves_per_simd * (double)ITERS * CHAINS;  // wave-instructions per SIMD
+        double ns_per_inst = ms * 1e6 / insts_per_simd;
+        printf("%-22s %8.3f ms  %6.3f ns/wave-inst/SIMD  = %5.2f cycles @2.4GHz\n", c.name, ms, ns_per_inst, ns_per_inst * 2.4);
+    }
+    return 0;
+}
