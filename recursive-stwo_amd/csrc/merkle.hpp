@@ -34,6 +34,17 @@ __device__ inline Hash8 sponge_capacity4(uint32_t v0, uint32_t v1, uint32_t v2, 
 __device__ inline Hash8 leaf_from_capacity(const Hash8& d) { return perm_rate(zero8(), d); }
 // hash_tree (primitives/merkle/src/lib.rs:9-11)
 __device__ inline Hash8 hash_tree(const Hash8& l, const Hash8& r) { return perm_rate(l, r); }
+// hash_tree_with_swap (primitives/merkle/src/lib.rs:22-30): ONE call site for both orders — a lane-divergent
+// `odd ? hash_tree(b, a) : hash_tree(a, b)` would run the permutation twice per wave with half the lanes masked.
+__device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, bool self_is_right) {
+    State16 st;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        st.s[i] = self_is_right ? sibling.w[i] : self.w[i];
+        st.s[8 + i] = self_is_right ? self.w[i] : sibling.w[i];
+    }
+    return rate_of(poseidon2(st));
+}
 // combine_hash_tree_with_column (primitives/merkle/src/lib.rs:43-48)
 __device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate(tree, col_cap); }
 

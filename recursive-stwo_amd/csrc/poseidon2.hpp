@@ -44,13 +44,14 @@ __constant__ uint32_t RC_PARTIAL[14] = {0x7f7ec4bf, 0x0421926f, 0x5198e669, 0x34
                                         0x66685c7f, 0x78d3249a, 0x60187881, 0x76dad67a, 0x0690b437,
                                         0x1ea95311, 0x40e5369a, 0x38f103fc, 0x1d226a21};
 
-__device__ __forceinline__ uint32_t pow5(uint32_t x) {
+// ---- straightforward canonical implementation (readable restatement; baseline of tools/perm_lab.hip)
+__device__ __forceinline__ uint32_t pow5_ref(uint32_t x) {
     uint32_t x2 = m_sqr(x);
     return m_mul(m_sqr(x2), x);
 }
 
 // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] in 8 additions, 2 doublings, 2 x4.
-__device__ __forceinline__ void mds4(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
+__device__ __forceinline__ void mds4_ref(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
     uint32_t t0 = m_add(x0, x1), t1 = m_add(x2, x3);
     uint32_t t2 = m_add(m_dbl(x1), t1), t3 = m_add(m_dbl(x3), t0);
     uint32_t t4 = m_add(m_shl(t1, 2), t3), t5 = m_add(m_shl(t0, 2), t2);
@@ -60,9 +61,9 @@ __device__ __forceinline__ void mds4(uint32_t& x0, uint32_t& x1, uint32_t& x2, u
     x3 = t4;
 }
 
-__device__ __forceinline__ void mds16(uint32_t* s) {
+__device__ __forceinline__ void mds16_ref(uint32_t* s) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) mds4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+    for (int g = 0; g < 4; g++) mds4_ref(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         uint32_t sum = m_add(m_add(s[j], s[j + 4]), m_add(s[j + 8], s[j + 12]));
@@ -71,17 +72,17 @@ __device__ __forceinline__ void mds16(uint32_t* s) {
     }
 }
 
-__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
-    mds16(s);
+__device__ __forceinline__ void poseidon2_ref_inline(uint32_t* s) {
+    mds16_ref(s);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = pow5(m_add(s[i], RC_FULL[r][i]));
-        mds16(s);
+        for (int i = 0; i < 16; i++) s[i] = pow5_ref(m_add(s[i], RC_FULL[r][i]));
+        mds16_ref(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 14; r++) {
-        s[0] = pow5(m_add(s[0], RC_PARTIAL[r]));
+        s[0] = pow5_ref(m_add(s[0], RC_PARTIAL[r]));
         // sum of all 16 words as a balanced tree
         uint32_t a0 = m_add(s[0], s[1]), a1 = m_add(s[2], s[3]), a2 = m_add(s[4], s[5]), a3 = m_add(s[6], s[7]);
         uint32_t a4 = m_add(s[8], s[9]), a5 = m_add(s[10], s[11]), a6 = m_add(s[12], s[13]),
@@ -94,8 +95,182 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
 #pragma unroll 1
     for (int r = 4; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = pow5(m_add(s[i], RC_FULL[r][i]));
-        mds16(s);
+        for (int i = 0; i < 16; i++) s[i] = pow5_ref(m_add(s[i], RC_FULL[r][i]));
+        mds16_ref(s);
+    }
+}
+
+
+// ===========================================================================================
+// Fast path.  Instruction costs measured on MI355X (tools/valu_lab.hip, 4 waves/SIMD):
+//   ~2.5 cycles : v_add_u32 v_sub_u32 v_and_b32 v_or_b32 v_lshrrev_b32 v_mov_b32 (also with a literal)
+//   ~4.3-4.6    : v_min_u32 v_lshlrev_b32 v_alignbit_b32 v_and_or_b32 v_mul_lo/hi_u32 v_lshl_add_u64
+//                 v_mad_u64_u32 (4.55; 5.05 with a live 64-bit addend)   -- the 32x32->64 multiply is
+//                 NOT quarter rate on gfx950, so the cost of a modular multiply is its reduction.
+// Consequences used below:
+//   * linear layers accumulate UNREDUCED in 64 bits (one v_lshl_add_u64 / v_mad_u64_u32 per term,
+//     shifts by 1..4 and small multipliers are free), and are folded once per round;
+//   * accumulators hold 2*v, so the Mersenne fold (v >> 31) + (v & P) is hi32 + (lo32 >> 1): two
+//     fast-class instructions instead of v_and + v_alignbit + v_add;
+//   * a product x*y is formed as (2x)*y for the same reason;
+//   * values between steps are only "weakly" reduced; the ranges are tracked in the comments:
+//       C  = [0, P]           (canonical, or P itself which is congruent to 0)
+//       L2 = [0, 2P]          (one conditional subtract away from C)
+//     Bit-exactness with the canonical reference (poseidon2_ref_inline) is tested on the GPU.
+// ===========================================================================================
+__device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int SH>
+__device__ __forceinline__ uint64_t shl_add64(uint64_t a, uint64_t b) {  // (a << SH) + b, SH in 1..4
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH));
+    return d;
+}
+// 32x32 -> 64 products and multiply-accumulates (v_mad_u64_u32).  The small constant multipliers are
+// passed as OPAQUE wave-uniform values (see opaque()): with a visible constant hipcc strength-reduces
+// a*2+c into slow-class shifts plus zero-extension moves instead of one v_mad_u64_u32.
+__device__ __forceinline__ uint32_t opaque(uint32_t k) {
+    uint32_t r;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "n"(k));
+    return r;
+}
+// The asm form (instead of `(uint64_t)a * b + c`) also keeps hipcc from re-associating
+// x0*k + x1*k into (x0 + x1)*k, which costs a 64-bit add, a 64x32 multiply and zero-extension moves.
+__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) {
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b_uniform, int) {  // b in an SGPR
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
+    return d;
+}
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b_uniform, uint64_t c) {  // a * b + c, b in an SGPR
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint64_t mad64u(uint32_t a_uniform, uint32_t b, uint64_t c) {  // a in an SGPR, b in a VGPR
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "s"(a_uniform), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t dbl32(uint32_t x) {  // x + x as a fast-class add (not a shift)
+    uint32_t d;
+    asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+// V = 2v with v < 2^62  ->  (v >> 31) + (v & P)
+__device__ __forceinline__ uint32_t fold2(uint64_t V) { return (uint32_t)(V >> 32) + ((uint32_t)V >> 1); }
+// t in [0, 2P] -> C
+__device__ __forceinline__ uint32_t canon(uint32_t t) { return min(t, t - P); }
+
+// x in C  ->  x^5 in L2
+__device__ __forceinline__ uint32_t pow5(uint32_t x) {
+    uint32_t c2 = canon(fold2(mul64(dbl32(x), x)));       // 2x^2 < 2^63; fold <= 2P-1
+    uint32_t c4 = canon(fold2(mul64(dbl32(c2), c2)));
+    return fold2(mul64(dbl32(c4), x));                    // hi <= P, lo>>1 <= P
+}
+
+// Y = 2*M4*(x0..x3) for 32-bit inputs (any u32), exact in 64 bits.
+__device__ __forceinline__ void mds4_2x(uint32_t k2, uint32_t k4, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                        uint64_t& y0, uint64_t& y1, uint64_t& y2, uint64_t& y3) {
+    uint64_t T0 = mad64(x0, k2, mul64(x1, k2, 0));           // 2(x0 + x1)
+    uint64_t T1 = mad64(x2, k2, mul64(x3, k2, 0));           // 2(x2 + x3)
+    uint64_t T2 = mad64(x1, k4, T1);                      // 2(2x1 + t1)
+    uint64_t T3 = mad64(x3, k4, T0);                      // 2(2x3 + t0)
+    uint64_t T4 = shl_add64<2>(T1, T3);                   // 2(4t1 + t3)
+    uint64_t T5 = shl_add64<2>(T0, T2);                   // 2(4t0 + t2)
+    y0 = add64(T3, T5);
+    y1 = T5;
+    y2 = add64(T2, T4);
+    y3 = T4;
+}
+
+// V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i]   (+ 2*rc[i] for i < n_rc), inputs any u32 (< 2^32):
+// every V[i] < 2 * 35 * 2^32 + 2^32 < 2^39.
+__device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, uint32_t v2, const uint32_t* s, uint64_t* V,
+                                         const uint32_t* rc, int n_rc) {
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            V[4 * g + j] = add64(V[4 * g + j], sum);
+            if (4 * g + j < n_rc) V[4 * g + j] = mad64u(rc[4 * g + j], v2, V[4 * g + j]);
+        }
+    }
+}
+
+__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
+    uint64_t V[16];
+    const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
+    uint32_t v2;  // the constant 2 in a VGPR (multiplier of the SGPR-resident round constants)
+    asm volatile("v_mov_b32 %0, 2" : "=v"(v2));
+    // s: canonical input.  After every full-round linear layer: s[i] = canon(fold2(V[i])) in C.
+    mds16_2x(k2, k4, v2, s, V, RC_FULL[0], 16);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));       // fold <= P + 71 <= 2P
+        if (r < 3) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
+        else mds16_2x(k2, k4, v2, s, V, RC_PARTIAL, 1);                                  // only lane 0 gets a constant
+    }
+    // partial rounds: lanes 1..15 stay lazily folded (< 2^31 + 2^18), lane 0 goes through the S-box
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
+    // 2 * diag: 2^(i+2) for lanes 1..15, as opaque wave-uniform multipliers
+    uint32_t kd[16];
+    kd[0] = k6;
+#define RSV_KD(i) kd[i] = opaque(4u << (i));
+    RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
+    RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
+#undef RSV_KD
+#pragma unroll 1
+    for (int r = 0; r < 14; r++) {
+        uint32_t u0 = pow5(canon(s[0]));                                     // s[0] <= 2P
+        // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
+        uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) { a = mad64(s[i], k2, a); b = mad64(s[i + 1], k2, b); }
+        uint64_t sum2 = add64(a, b);
+        // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50
+        uint64_t v0 = mad64(u0, k6, sum2);
+        if (r < 13) {
+            s[0] = fold2(mad64u(RC_PARTIAL[r + 1], v2, v0));
+#pragma unroll
+            for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
+        } else {
+            // the constants of the next full round ride on the accumulators
+            s[0] = fold2(mad64u(RC_FULL[4][0], v2, v0));
+#pragma unroll
+            for (int i = 1; i < 16; i++) s[i] = fold2(mad64u(RC_FULL[4][i], v2, mad64(s[i], kd[i], sum2)));
+        }
+    }
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) {
+        if (r == 4) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = pow5(canon(s[i]));           // s[i] < 2^31 + 2^19 <= 2P
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));
+        }
+        if (r < 7) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
+        else mds16_2x(k2, k4, v2, s, V, nullptr, 0);
+    }
+    // canonical output: fold <= P + 70, so one conditional subtract lands in [0, P); P itself maps to 0
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t t = fold2(V[i]);
+        s[i] = min(t, t - P);
     }
 }
 

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
                 else { sib = zero8(); bad = true; }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
-            cur = odd ? hash_tree(sib, cur) : hash_tree(cur, sib);
+            cur = hash_tree_swap(cur, sib, odd);
             const uint32_t pl_ = lvl - 1;  // parent level
             uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));
             if (nc) {
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
                 }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
-            cur = odd ? hash_tree(sibh, cur) : hash_tree(cur, sibh);
+            cur = hash_tree_swap(cur, sibh, odd);
             have_sib = false;
         }
         // phase B: data level of the first-layer tree: fold in the column and build the sibling node
