@@ -144,6 +144,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     atomicMax(&summary[0], nq);
     atomicMax(&summary[1], M);
     atomicMax(&summary[2], n_inner);
+    atomicMax(&summary[3], 64u - (last + b + 1u));  // 64 - (lowest data / leaf level of any tree)
 }
 
 // ------------------------------------------------------------------- k_scan
@@ -804,12 +805,85 @@ struct MerkleArgs {
     PlanPtrs pl;
     const uint32_t* leafv;
     uint32_t maxInner;
+    uint32_t Lc;  // cap level: levels below Lc are hashed by merkle_cap (0 = walk every path to the root)
 };
+
+// ---------------------------------------------------------------- merkle_cap
+// Top of a tree.  Below level Lc (2^Lc <= queries per proof) the query paths of a proof have merged into
+// at most 2^l distinct nodes per level, so continuing one-lane-per-path would hash every shared node up to
+// n_queries times.  Here the lanes of the workgroup are re-dealt densely over (proof, node position): level
+// l costs per_block * 2^l lanes instead of per_block * G.  Nodes live in LDS (xch, two buffers), presence
+// in a per-proof bitmask; a missing child is the next hash_witness entry in ascending node order, exactly
+// the batched order of components/hints/src/decommit.rs:91-139 and folding.rs:116-206.
+struct CapGroup {
+    const uint32_t* hw;    // hash witness of this (proof, tree)
+    const uint32_t* lvl;   // PlanHdr::lvl
+    const uint16_t* wf;    // PlanHdr::wf (first-layer pair tree) or nullptr
+    const uint32_t* root;  // expected root (8 words)
+    uint32_t* flags;       // ProofCtx::flags
+    uint32_t hw_n, s_top, active, fail_bit;
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
+                                           uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
+                                           const Hash8& cur) {
+    const uint32_t t = threadIdx.x;
+    __syncthreads();  // xch is free, descriptors written
+    if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
+    __syncthreads();
+    if (live) {
+        store_hash(xch[0][(grp << Lc) + pos], cur);
+        atomicOr(&mask[0][grp], 1ull << pos);
+    }
+    __syncthreads();
+    uint32_t bufi = 0;
+    for (uint32_t l = Lc; l-- > 0;) {  // parent level
+        const uint32_t g2 = t >> l, ppos = t & ((1u << l) - 1u);
+        if (g2 < per_block && grp_desc[g2].active) {
+            const CapGroup& d = grp_desc[g2];
+            const unsigned long long cm = mask[bufi][g2];
+            const uint32_t pres = (uint32_t)(cm >> (2 * ppos)) & 3u;
+            if (pres) {
+                const unsigned long long even = 0x5555555555555555ull;
+                const unsigned long long lack = (cm ^ (cm >> 1)) & even;  // bit 2p': exactly one child present
+                const uint32_t rank = __popcll(lack & ((1ull << (2 * ppos)) - 1ull));
+                const uint32_t base = d.wf ? (uint32_t)d.wf[l + 1] : lvl_s(d.lvl[l + 2]) - d.s_top;
+                const uint32_t* kids = &xch[bufi][(g2 << (l + 1)) + 2 * ppos][0];
+                Hash8 left, right;
+                bool bad = false;
+                if (pres == 3u) { left = load_hash(kids); right = load_hash(kids + 8); }
+                else {
+                    const uint32_t wi = base + rank;
+                    Hash8 w8 = zero8();
+                    if (wi < d.hw_n) w8 = load_hash(d.hw + 8 * wi);
+                    else bad = true;
+                    left = (pres & 1u) ? load_hash(kids) : w8;
+                    right = (pres & 2u) ? load_hash(kids + 8) : w8;
+                }
+                Hash8 node = hash_tree(left, right);
+                if (l == 0) {
+                    if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, 1u << d.fail_bit);
+                } else {
+                    if (bad) atomicOr(d.flags, 1u << d.fail_bit);
+                    store_hash(xch[bufi ^ 1][(g2 << l) + ppos], node);
+                    atomicOr(&mask[bufi ^ 1][g2], 1ull << ppos);
+                }
+            }
+        }
+        __syncthreads();
+        if (t < per_block) mask[bufi][t] = 0;
+        bufi ^= 1;
+        __syncthreads();
+    }
+}
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     __shared__ uint32_t xch[2][BLOCK][8];
-    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
+    __shared__ CapGroup capgrp[64];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t p = blockIdx.x * per_block + grp;
     const int t = blockIdx.y;
@@ -839,7 +913,15 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         if (off + nc_leaf > qv_n) bad = true;
         else cur = leaf_from_capacity(sponge_capacity(qv + off, nc_leaf));
     }
-    for (uint32_t lvl = a.pl.maxM; lvl >= 1; lvl--) {  // child level
+    if (Lc && j == 0 && grp < per_block) {
+        CapGroup& d = capgrp[grp];
+        d.active = live ? 1u : 0u;
+        if (live) {
+            d.hw = hw; d.hw_n = hw_n; d.lvl = h->lvl; d.wf = nullptr; d.s_top = s_top;
+            d.root = w + W_COMMIT0 + 8 * t; d.flags = &a.ctxs[p].flags; d.fail_bit = R_MERKLE_T0 + t;
+        }
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
         const uint32_t buf = lvl & 1u;
         const bool on = live && lvl <= mx;
         if (on) store_hash(xch[buf][threadIdx.x], cur);
@@ -870,9 +952,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         uint32_t nc_lower = (t == 3 || A == B) ? 0u : (lower == A ? plonk_cols(t) : poseidon_cols(t));
         uint32_t want_qv = nd_leaf * nc_leaf + (lower ? lvl_nd(h->lvl[lower]) * nc_lower : 0u);
         uint32_t want_hw = lvl_s(h->lvl[1]) - s_top;
-        bool ok = !bad && want_qv == qv_n && want_hw == hw_n && hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t));
+        bool ok = !bad && want_qv == qv_n && want_hw == hw_n && (Lc || hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t)));
         if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (R_MERKLE_T0 + t));
     }
+    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur);
 }
 
 // ------------------------------------------------------------ k_pair_merkle
@@ -882,7 +965,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     __shared__ uint32_t xch[2][BLOCK][8];
-    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
+    __shared__ CapGroup capgrp[64];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t p = blockIdx.x * per_block + grp;
     const uint32_t slot = blockIdx.y;
@@ -914,7 +999,15 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
         have_sib = true;
         dslot = 0;
     }
-    for (uint32_t lvl = a.pl.maxM; lvl >= 1; lvl--) {  // child level
+    if (Lc && j == 0 && grp < per_block) {
+        CapGroup& d = capgrp[grp];
+        d.active = live ? 1u : 0u;
+        if (live) {
+            d.hw = w + L->hash_off; d.hw_n = L->hash_n; d.lvl = h->lvl; d.wf = slot == 0 ? h->wf : nullptr; d.s_top = s_top;
+            d.root = w + L->commit_off; d.flags = &a.ctxs[p].flags; d.fail_bit = slot == 0 ? R_FRI_FIRST : R_FRI_INNER;
+        }
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
         const bool on = live && lvl <= top;
         const uint32_t pl_ = lvl - 1;
         // is the parent level a data level of the first-layer tree?
@@ -965,9 +1058,10 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     }
     if (live) {
         uint32_t want_hw = slot == 0 ? (uint32_t)h->wf_total : lvl_s(h->lvl[1]) - s_top;
-        bool ok = !bad && want_hw == L->hash_n && hash_eq(cur, load_hash(w + L->commit_off));
+        bool ok = !bad && want_hw == L->hash_n && (Lc || hash_eq(cur, load_hash(w + L->commit_off)));
         if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER));
     }
+    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur);
 }
 
 // --------------------------------------------------------------- k_finalize
