@@ -62,6 +62,25 @@ int main(int argc, char** argv) {
         }
         printf("variant %d: %.3f ms for %zu x %d perms = %.3f G perms/s\n", v, ms[v], n, reps, n * (double)reps / ms[v] / 1e6);
     }
+    {   // latency mode: exactly one wave per SIMD, 64 sequential permutations per lane
+        size_t nl = 256 * 256;
+        for (int v = 0; v < 3; v++) {
+            float t = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                hipEventRecord(e0);
+                if (v == 0) hipLaunchKernelGGL(k_perm<0>, dim3(nl / 256), dim3(256), 0, 0, (const uint4*)din, (uint4*)d1, nl, 64);
+                else if (v == 1) hipLaunchKernelGGL(k_perm<1>, dim3(nl / 256), dim3(256), 0, 0, (const uint4*)din, (uint4*)d1, nl, 64);
+                else hipLaunchKernelGGL(k_perm<2>, dim3(nl / 256), dim3(256), 0, 0, (const uint4*)din, (uint4*)d1, nl, 64);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&t, e0, e1);
+            }
+            printf("latency mode variant %d: %.3f ms for 64 sequential perms/lane at 1 wave/SIMD = %.2f us per perm-step\n", v, t, t * 1000 / 64);
+        }
+        // restore d1 for the comparison below
+        hipLaunchKernelGGL(k_perm<2>, dim3(n / 256), dim3(256), 0, 0, (const uint4*)din, (uint4*)d1, n, reps);
+        hipDeviceSynchronize();
+    }
     std::vector<uint32_t> o0(16 * n), o1(16 * n);
     hipMemcpy(o0.data(), d0, 64 * n, hipMemcpyDeviceToHost);
     hipMemcpy(o1.data(), d1, 64 * n, hipMemcpyDeviceToHost);
