@@ -277,9 +277,9 @@ class Context:
                                          d_count.data_ptr() if d_count is not None else None), "rsv_accept_bitmap_dev")
 
     def last_stage_times(self) -> dict:
-        names = (ctypes.c_char_p * 8)()
-        ms = (ctypes.c_float * 8)()
-        k = lib.rsv_last_stage_times(self._h, names, ms, 8)
+        names = (ctypes.c_char_p * 16)()
+        ms = (ctypes.c_float * 16)()
+        k = lib.rsv_last_stage_times(self._h, names, ms, 16)
         if k < 0:
             raise RsvError(k, "rsv_last_stage_times")
         return {names[i].decode(): float(ms[i]) for i in range(k)}

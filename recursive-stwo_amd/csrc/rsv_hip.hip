@@ -35,6 +35,8 @@ void destroy_verify_state(VerifyState*);
 struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -82,8 +84,11 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     rsv_ctx* c = new (std::nothrow) rsv_ctx();
     if (!c) return RSV_E_DEVICE;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
     }
     *out = c;
@@ -93,7 +98,11 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
 void rsv_ctx_destroy(rsv_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_pi) (void)hipFree(c->d_pi);
