@@ -669,6 +669,26 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     uint32_t qj = live ? c->q[j] : 0;
     uint32_t n_sizes = live ? c->n_sizes : 0;
     QM31 first[3];
+    // Domain points.  One scalar multiplication gives the point of the query at level M; the points at the
+    // smaller column sizes follow by the doubling map pi(x, y) = (2x^2 - 1, 2xy): doubling the level-l point of
+    // position pos gives the level-(l-1) point of pos >> 1 up to the sign of y, which is fixed by bit 0 of the
+    // respective positions (CanonicCoset::circle_domain().at(bit_reverse(.))).
+    CPoint dp[3];
+    if (live) {
+        CPoint cur = domain_point(M, qj);
+        uint32_t lvl = M;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            const uint32_t l = c->sizes[g];
+            while (lvl > l) {
+                const uint32_t pos = qj >> (M - lvl);
+                uint32_t y2 = m_dbl(m_mul(cur.x, cur.y));
+                cur.x = m_sub(m_dbl(m_sqr(cur.x)), 1u);
+                cur.y = ((pos ^ (pos >> 1)) & 1u) ? m_neg(y2) : y2;
+                lvl--;
+            }
+            dp[g] = cur;
+        }
+    }
     // ---- DEEP quotients + first-layer fold, per column log size
     for (uint32_t g = 0; g < 3; g++) {
         QM31 answer = q_zero();
@@ -708,13 +728,12 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
                     }
                 }
             }
-            CPoint dp = domain_point(l, pos);
             for (uint32_t bi = 0; bi < c->n_batches[g]; bi++) {
                 const QBatch& qb = c->batch[g][bi];
                 CM31 prx = c_mk(qb.prx[0], qb.prx[1]), pix = c_mk(qb.pix[0], qb.pix[1]);
                 CM31 pry = c_mk(qb.pry[0], qb.pry[1]), piy = c_mk(qb.piy[0], qb.piy[1]);
-                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dp.y), ldq(qb.sb)));
-                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dp.x, 0)), piy), c_mul(c_sub(pry, c_mk(dp.y, 0)), pix));
+                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dp[g].y), ldq(qb.sb)));
+                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dp[g].x, 0)), piy), c_mul(c_sub(pry, c_mk(dp[g].y, 0)), pix));
                 answer = q_add(answer, q_mul_c(num, c_inv(den)));
             }
         }
@@ -731,15 +750,20 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
             }
             uint32_t* lv = leafv + ((size_t)g * G + j) * 8;
             stq(lv, answer); stq(lv + 4, sib);
-            // fold circle -> line with 1/y of the pair's base point (folding/src/lib.rs:57-90)
-            CPoint bp = domain_point(l, pos & ~1u);
-            first[g] = fold_pair(answer, sib, pos & 1u, m_inv(bp.y), ldq(c->fri_alpha[M - l]));
+            // fold circle -> line with 1/y of the pair's base point (folding/src/lib.rs:57-90); the base
+            // point (bit 0 of the position cleared) is the conjugate of this point when the position is odd
+            uint32_t by = (pos & 1u) ? m_neg(dp[g].y) : dp[g].y;
+            first[g] = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
         }
         __syncthreads();
     }
     // ---- inner layers (folding/src/lib.rs:120-192)
+    // x-coordinate of the pair base point at line-domain level l: X_{M-1} = +-x_M and X_{l-1} = +-(2 X_l^2 - 1)
+    // (half_odds(l).at(i) doubles to half_odds(l-1).at(i mod 2^(l-1)); clearing bit 0 of an odd position moves
+    // the bit-reversed index by half the coset = the point (-1, 0), i.e. negates x).
     QM31 folded = q_zero();
     uint32_t l = M;
+    uint32_t X = live ? dp[0].x : 0u;
     for (uint32_t i = 0; i < a.maxInner; i++) {
         bool on = live && i < m->n_inner;
         if (on) {
@@ -765,28 +789,46 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
             if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= 1u << R_FRI_INNER;  // hints/src/folding.rs:558
             uint32_t* lv = leafv + ((size_t)(3 + i) * G + j) * 8;
             stq(lv, folded); stq(lv + 4, sib);
-            uint32_t x = half_odds_at(l, bit_reverse(pos & ~1u, l)).x;
-            folded = fold_pair(folded, sib, pos & 1u, m_inv(x), ldq(c->fri_alpha[i + 1]));
+            uint32_t xr = (i == 0) ? X : m_sub(m_dbl(m_sqr(X)), 1u);
+            X = (pos & 1u) ? m_neg(xr) : xr;
+            folded = fold_pair(folded, sib, pos & 1u, m_inv(X), ldq(c->fri_alpha[i + 1]));
         }
         __syncthreads();
     }
     // ---- last layer (folding/src/lib.rs:194-204, primitives/line/src/lib.rs:39-67)
     if (live) {
-        uint32_t ll = l - 1, idx = (qj >> (M - l)) >> 1;
-        uint32_t x = half_odds_at(ll, bit_reverse(idx, ll)).x;
-        uint32_t log_n = m->log_last;
-        // fold(coeffs, [x, pi(x), ...]): evaluate bottom-up; coefficient i is
-        // weighted by prod_k d[k]^(bit (log_n-1-k) of i)
+        // x of half_odds(l-1).at(bit_reverse(pos >> 1)) = pi(X_l) (for a proof without inner layers: pi of x_M)
+        uint32_t x = m_sub(m_dbl(m_sqr(X)), 1u);
+        const uint32_t log_n = m->log_last;
+        // fold(coeffs, [x, pi(x), ...]) = sum_i coeff_i * prod_k d[k]^(bit (log_n-1-k) of i).  The weights
+        // factor into a table over the low 4 index bits (registers) times a product over the high bits.
         uint32_t d[16];
-        for (uint32_t k = 0; k < log_n; k++) { d[k] = x; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+        for (uint32_t k = 0; k < 16; k++) { d[k] = (k < log_n) ? x : 1u; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+        const uint32_t nlo = log_n < 4 ? log_n : 4u;
+        uint32_t wl[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) wl[t] = 1u;
+        // low index bit b pairs with d[log_n - 1 - b]
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t db = (uint32_t)b < nlo ? d[(log_n - 1 - b) & 15u] : 1u;
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+                if (t & (1 << b)) wl[t] = m_mul(wl[t], db);
+        }
         QM31 acc = q_zero();
         const uint32_t* cf = w + m->last_off;
+        const uint32_t n_hi = m->last_n >> nlo, n_lo = 1u << nlo;
 #pragma unroll 1
-        for (uint32_t ci = 0; ci < m->last_n; ci++) {
-            uint32_t wgt = 1;
-            for (uint32_t k = 0; k < log_n; k++)
-                if ((ci >> (log_n - 1 - k)) & 1u) wgt = m_mul(wgt, d[k]);
-            acc = q_add(acc, q_mul_m(ldq(cf + 4 * ci), wgt));
+        for (uint32_t hi = 0; hi < n_hi; hi++) {
+            uint32_t wh = 1u;
+            for (uint32_t b = 0; b + nlo < log_n; b++)
+                if ((hi >> b) & 1u) wh = m_mul(wh, d[(log_n - 1 - nlo - b) & 15u]);
+            QM31 inner = q_zero();
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+                if ((uint32_t)t < n_lo) inner = q_add(inner, q_mul_m(ldq(cf + 4 * ((hi << nlo) + t)), wl[t]));
+            acc = q_add(acc, q_mul_m(inner, wh));
         }
         if (!q_eq(acc, folded)) flags |= 1u << R_FRI_LAST;
     }
