@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -38,8 +39,10 @@ struct rsv_ctx {
     hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
-    void* ws = nullptr;
+    void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
+    void* ws_fixed = nullptr;  // per-proof records of the current batch
+    size_t ws_fixed_bytes = 0;
     VerifyState* vs = nullptr;
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
@@ -105,6 +108,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->ws_fixed) (void)hipFree(c->ws_fixed);
     if (c->d_pi) (void)hipFree(c->d_pi);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -127,6 +131,7 @@ int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out,
     // the range flag lives at the start of the workspace
     if (c->ws_bytes < 256) {
         if (c->ws) (void)hipFree(c->ws);
+    if (c->ws_fixed) (void)hipFree(c->ws_fixed);
         c->ws = nullptr; c->ws_bytes = 0;
         HIP_TRY(hipMalloc(&c->ws, 1 << 20));
         c->ws_bytes = 1 << 20;

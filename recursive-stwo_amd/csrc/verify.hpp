@@ -87,11 +87,13 @@ __device__ inline void parse_fri_layer(WordReader& r, FriLayerRef& l) {
 
 __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                               uint32_t n, CfgOpt cfg, ProofMeta* __restrict__ metas,
-                                              ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ summary) {
+                                              ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ summary,
+                                              uint32_t* __restrict__ shape) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     ProofMeta& m = metas[p];
     ctxs[p].flags = 0;
+    shape[p] = 0;
     uint64_t o0 = offsets[p], o1 = offsets[p + 1];
     m.reason = R_PARSE;
     m.nq = 0; m.M = 0; m.n_inner = 0;
@@ -145,6 +147,11 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     atomicMax(&summary[1], M);
     atomicMax(&summary[2], n_inner);
     atomicMax(&summary[3], 64u - (last + b + 1u));  // 64 - (lowest data / leaf level of any tree)
+    // shape word for host-side bucketing + "is the batch uniform" summary (max of x and of ~x)
+    const uint32_t sw = nq | (M << 8) | (n_inner << 16) | ((last + b + 1u) << 24);
+    shape[p] = sw;
+    atomicMax(&summary[4], sw);
+    atomicMax(&summary[5], ~sw);
 }
 
 // ------------------------------------------------------------------- k_scan
@@ -441,11 +448,17 @@ __global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, c
 // sibling, which witness index each lane consumes; see layout.hpp) and the
 // per-proof constants of the DEEP quotients
 // (components/recursive/answer/src/data_structures.rs:132-189).
+// The per-query stages address their workspace by SLOT (position inside the current launch) and the
+// per-proof records / the blob by PROOF index: proof = ids ? ids[slot] : p0 + slot.  A batch of mixed shapes
+// is bucketed by n_queries on the host so that every launch uses G = that bucket's n_queries lanes per proof.
 struct PlanPtrs {
     PlanHdr* hdr;
-    uint32_t* ent;  // [n][(maxM+1) * G]
-    uint32_t* fl;   // [n][2 * G]
+    uint32_t* ent;  // [slots][(maxM+1) * G]
+    uint32_t* fl;   // [slots][2 * G]
     uint32_t G, maxM;
+    const uint32_t* ids;  // slot -> proof index (nullptr: proof = p0 + slot)
+    uint32_t p0;
+    __device__ uint32_t proof_of(uint32_t slot) const { return ids ? ids[slot] : p0 + slot; }
 };
 
 __device__ inline int sample_index(int t, int col, int s) {
@@ -458,8 +471,9 @@ __device__ inline int sample_index(int t, int col, int s) {
 __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                              uint32_t n, const ProofMeta* __restrict__ metas,
                                              ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t p = pl.proof_of(slot);
     const ProofMeta& m = metas[p];
     if (m.reason != R_OK) return;
     ProofCtx& c = ctxs[p];
@@ -483,9 +497,9 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
     c.n_sizes = n_sizes;
     if (n_sizes < 3) c.sizes[2] = 0;
 
-    PlanHdr& h = pl.hdr[p];
-    uint32_t* ent = pl.ent + (size_t)p * (pl.maxM + 1) * G;
-    uint32_t* fl = pl.fl + (size_t)p * 2 * G;
+    PlanHdr& h = pl.hdr[slot];
+    uint32_t* ent = pl.ent + (size_t)slot * (pl.maxM + 1) * G;
+    uint32_t* fl = pl.fl + (size_t)slot * 2 * G;
     // generic tables, node level l = M .. 1 (children of level l-1)
     uint32_t suffix = 0;
     h.lvl[M + 1] = 0;
@@ -654,15 +668,16 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     __shared__ uint32_t xq[BLOCK][4];
     const uint32_t G = a.pl.G, per_block = BLOCK / G;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t p = blockIdx.x * per_block + grp;
-    bool live = grp < per_block && p < a.n;
+    const uint32_t slot = blockIdx.x * per_block + grp;
+    bool live = grp < per_block && slot < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq;
     ProofCtx* c = live ? &a.ctxs[p] : nullptr;
     const uint32_t* w = live ? reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]) : nullptr;
-    const uint32_t* ent = live ? a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G : nullptr;
-    const PlanHdr* h = live ? &a.pl.hdr[p] : nullptr;
-    uint32_t* leafv = live ? a.leafv + ((size_t)p * (3 + a.maxInner)) * G * 8 : nullptr;
+    const uint32_t* ent = live ? a.pl.ent + (size_t)slot * (a.pl.maxM + 1) * G : nullptr;
+    const PlanHdr* h = live ? &a.pl.hdr[slot] : nullptr;
+    uint32_t* leafv = live ? a.leafv + ((size_t)slot * (3 + a.maxInner)) * G * 8 : nullptr;
     const uint32_t gbase = grp * G;
     uint32_t flags = 0;
     uint32_t M = live ? m->M : 0, A = live ? m->A : 0, B = live ? m->B : 0;
@@ -927,9 +942,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     __shared__ CapGroup capgrp[64];
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t p = blockIdx.x * per_block + grp;
+    const uint32_t slot_ = blockIdx.x * per_block + grp;
     const int t = blockIdx.y;
-    bool live = grp < per_block && p < a.n;
+    bool live = grp < per_block && slot_ < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq;
     const uint32_t gbase = grp * G;
@@ -941,8 +957,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     uint32_t qj = 0;
     if (live) {
         w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
-        ent = a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G;
-        h = &a.pl.hdr[p];
+        ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
+        h = &a.pl.hdr[slot_];
         M = m->M; A = m->A; B = m->B;
         mx = (t == 3) ? M : umax(A, B);
         nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
@@ -1011,9 +1027,10 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     __shared__ CapGroup capgrp[64];
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t p = blockIdx.x * per_block + grp;
+    const uint32_t slot_ = blockIdx.x * per_block + grp;
     const uint32_t slot = blockIdx.y;
-    bool live = grp < per_block && p < a.n;
+    bool live = grp < per_block && slot_ < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq && (slot == 0 || slot - 1 < m->n_inner);
     const uint32_t gbase = grp * G;
@@ -1025,16 +1042,16 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     Hash8 cur = zero8(), sibh = zero8();
     if (live) {
         w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
-        ent = a.pl.ent + (size_t)p * (a.pl.maxM + 1) * G;
-        fl = a.pl.fl + (size_t)p * 2 * G;
-        h = &a.pl.hdr[p];
+        ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
+        fl = a.pl.fl + (size_t)slot_ * 2 * G;
+        h = &a.pl.hdr[slot_];
         c = &a.ctxs[p];
         M = m->M;
         L = slot == 0 ? &m->first : &m->inner[slot - 1];
         top = slot == 0 ? M : M - slot;  // leaf level of this tree
         qj = c->q[j];
         s_top = lvl_s(h->lvl[top]);
-        leafv = a.leafv + ((size_t)p * (3 + a.maxInner)) * G * 8;
+        leafv = a.leafv + ((size_t)slot_ * (3 + a.maxInner)) * G * 8;
         const uint32_t* lv = leafv + ((size_t)(slot == 0 ? 0 : 2 + slot) * G + j) * 8;
         cur = leaf_from_capacity(sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
         sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));

@@ -206,3 +206,77 @@ def test_device_resident_api_and_bitmap(rsv):
     times = ctx.last_stage_times()
     assert set(times) >= {"trace_merkle", "pair_merkle", "transcript"} and all(v >= 0 for v in times.values())
     ctx.close()
+
+
+def _corrupt(proof: bytes, rng, region_end: int, n_bytes: int) -> bytes:
+    b = bytearray(proof)
+    for _ in range(n_bytes):
+        b[int(rng.integers(0, region_end))] = int(rng.integers(0, 256))
+    return bytes(b)
+
+
+def test_fuzzed_headers_and_prefixes_match_oracle(rsv):
+    """Robustness: random byte corruption of the header / length-prefix areas (and of whole proofs) must never
+    fault and must give the oracle's verdict and reason (mostly RSV_R_PARSE)."""
+    rng = np.random.default_rng(11)
+    small = read_proof("small_proof.bin")
+    big = read_proof("level2-1.bin")
+    batch = []
+    for k in range(48):
+        batch.append(_corrupt(small, rng, 64, 1 + k % 3))           # header words
+    for k in range(48):
+        batch.append(_corrupt(small, rng, 3620, 1 + k % 4))         # constant-shape prefix + first prefixes
+    for k in range(32):
+        batch.append(_corrupt(small, rng, len(small), 8))           # anywhere
+    # length prefixes of the variable part: overwrite a u64 prefix with a huge / odd count
+    for off in (3580, 3588, 3596):
+        for val in (0, 1, 5, 0xFFFFFFFF, 1 << 40):
+            b = bytearray(small)
+            b[off:off + 8] = int(val).to_bytes(8, "little")
+            batch.append(bytes(b))
+    acc, reason = rsv.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    oacc, oreason = ob.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    assert acc.tolist() == oacc.tolist()
+    assert reason.tolist() == oreason.tolist()
+    batch2 = [_corrupt(big, rng, 3620, 2) for _ in range(16)] + [big]
+    acc, reason = rsv.verify_batch(batch2)
+    oacc, oreason = ob.verify_batch(batch2)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    assert acc[-1] == 1
+
+
+def test_chunked_workspace_matches_unchunked(rsv, monkeypatch):
+    """A small workspace budget forces the per-query stages to run in several chunks."""
+    import torch
+    proof = read_proof("small_proof.bin")
+    n = 2600
+    batch = [ob.tamper(proof, i) if i % 11 == 4 else proof for i in range(n)]
+    blob, offsets = rsv.pack(batch)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    results = []
+    for budget in ("64", "8192"):
+        monkeypatch.setenv("RSV_WS_BUDGET_MB", budget)
+        ctx = rsv.Context(0)
+        d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, inputs=[(1, (1, 0, 0, 0))])
+        ctx.synchronize()
+        results.append((d_acc.cpu().numpy().tolist(), d_reason.cpu().numpy().tolist()))
+        ctx.close()
+    assert results[0] == results[1]
+    want = [0 if i % 11 == 4 else 1 for i in range(n)]
+    assert results[0][0] == want
+
+
+def test_cap_disabled_matches_cap_enabled(rsv, monkeypatch):
+    """RSV_CAP=0 walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
+    proof = read_proof("recursive_proof_16_15.bin")
+    batch = [ob.tamper(proof, i) for i in range(48)] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
+    monkeypatch.setenv("RSV_CAP", "0")
+    a0, r0 = rsv.verify_batch(batch)
+    monkeypatch.setenv("RSV_CAP", "1")
+    a1, r1 = rsv.verify_batch(batch)
+    assert a0.tolist() == a1.tolist() and r0.tolist() == r1.tolist()
+    assert a1[-3:].tolist() == [1, 1, 1]
