@@ -25,6 +25,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FIXTURES = ["recursive_proof_16_15.bin", "level3-1.bin", "level6-1.bin", "level7-1.bin"]
+# other workloads (parity-test configurations of BASELINE.json, selectable with --workload; not the bench line)
+WORKLOADS = {
+    "standard": FIXTURES,                                   # BASELINE configs[2]
+    "copies": ["recursive_proof_16_15.bin"],                # BASELINE configs[1]: copies of one proof
+    "chain": ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin",
+              "level7-1.bin", "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin",
+              "level13-1.bin"],                             # BASELINE configs[4]: recursion chain, mixed shapes
+}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -41,10 +49,10 @@ def read_fixture(name):
         return f.read()
 
 
-def build_batch_on_device(torch, dev, n_proofs, first_index):
+def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
     """Returns (d_blob uint8, d_offsets int64[n+1], lengths, tamper byte offsets) for global proof
     indices [first_index, first_index + n_proofs)."""
-    proofs = [read_fixture(f) for f in FIXTURES]
+    proofs = [read_fixture(f) for f in fixtures]
     lens = np.array([len(p) for p in proofs], dtype=np.int64)
     idx = (np.arange(n_proofs, dtype=np.int64) + first_index) % len(proofs)
     plen = lens[idx]
@@ -104,6 +112,7 @@ def main():
     ap.add_argument("--proofs", type=int, default=65536, help="proofs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="oracle sample size (0 = skip, -1 = auto)")
     ap.add_argument("--perm-log2", type=int, default=24, help="Poseidon2 microbench size (log2 states, 0 = skip)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="standard")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +136,8 @@ def main():
 
     n = args.proofs
     first = rank * n
-    d_blob, d_offsets, plen, tam = build_batch_on_device(torch, dev, n, first)
+    fixtures = WORKLOADS[args.workload]
+    d_blob, d_offsets, plen, tam = build_batch_on_device(torch, dev, n, first, fixtures)
     total_bytes = int(plen.sum())
     d_accept = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -241,7 +251,7 @@ def main():
         "metric": "recursive proofs verified/sec", "value": value, "unit": "proofs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31 modular integers)", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: {n} proofs/GPU round-robin over {FIXTURES}, i%17==5 tampered "
+        "config": {"workload": f"{'BASELINE configs[2]' if args.workload == 'standard' else args.workload}: {n} proofs/GPU round-robin over {fixtures}, i%17==5 tampered "
                                f"(SURVEY §8d), full verify; bit-exact accept map checked",
                    "proofs_per_gpu": n, "bytes_per_gpu": total_bytes, "parallelism": f"shard{world}"},
         "roofline": roofline, "cpu_baseline": cpu, "valu": valu,

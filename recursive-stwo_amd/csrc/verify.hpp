@@ -471,6 +471,7 @@ __device__ inline int sample_index(int t, int col, int s) {
 __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                              uint32_t n, const ProofMeta* __restrict__ metas,
                                              ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+    __shared__ uint32_t sq[MAXQ][64];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t p = pl.proof_of(slot);
@@ -480,15 +481,18 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     const uint32_t nq = m.nq, M = m.M, A = m.A, B = m.B, G = pl.G;
     uint32_t flags = 0;
-    // query positions (primitives/query/src/lib.rs:19-38), sorted ascending
+    // query positions (primitives/query/src/lib.rs:19-38), sorted ascending.  The sorted list is walked
+    // M times below, so it lives in LDS (k-major: the 64 lanes of the block hit 64 different banks).
+#define SQ(k) sq[(k)][threadIdx.x]
     for (uint32_t j = 0; j < nq; j++) {
         uint32_t v = c.raw_q[j] & ((1u << M) - 1u);
         uint32_t k = j;
-        while (k > 0 && c.q[k - 1] > v) { c.q[k] = c.q[k - 1]; k--; }
-        c.q[k] = v;
+        while (k > 0 && SQ(k - 1) > v) { SQ(k) = SQ(k - 1); k--; }
+        SQ(k) = v;
     }
+    for (uint32_t j = 0; j < nq; j++) c.q[j] = SQ(j);
     for (uint32_t j = 0; j + 1 < nq; j++)
-        if (c.q[j] == c.q[j + 1]) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
+        if (SQ(j) == SQ(j + 1)) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
     // column log sizes, descending
     uint32_t n_sizes = 0;
     c.sizes[n_sizes++] = M;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
             uint32_t a = k;
             int split = -1;
             while (k + 1 < nq) {
-                uint32_t x = c.q[k] ^ c.q[k + 1];
+                uint32_t x = SQ(k) ^ SQ(k + 1);
                 int d = x ? 31 - __clz(x) : -1;
                 if (d > (int)sh) break;
                 if (d == (int)sh) split = (int)k;
@@ -553,18 +557,18 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
             uint32_t k = 0;
             while (k < nq) {
                 uint32_t a = k;
-                uint32_t node = c.q[k] >> sh;
+                uint32_t node = SQ(k) >> sh;
                 bool has_both_children = false;
-                while (k + 1 < nq && (c.q[k + 1] >> sh) == node) {
-                    if (((c.q[k] >> (sh - 1)) ^ (c.q[k + 1] >> (sh - 1))) & 1u) has_both_children = true;
+                while (k + 1 < nq && (SQ(k + 1) >> sh) == node) {
+                    if (((SQ(k) >> (sh - 1)) ^ (SQ(k + 1) >> (sh - 1))) & 1u) has_both_children = true;
                     k++;
                 }
                 uint32_t bnd = k;
                 k++;
                 uint32_t lack = (!child_data && !has_both_children) ? 1u : 0u;
                 if (data) {
-                    bool sib_present = (a > 0 && (c.q[a - 1] >> sh) == (node ^ 1u)) ||
-                                       (bnd + 1 < nq && (c.q[bnd + 1] >> sh) == (node ^ 1u));
+                    bool sib_present = (a > 0 && (SQ(a - 1) >> sh) == (node ^ 1u)) ||
+                                       (bnd + 1 < nq && (SQ(bnd + 1) >> sh) == (node ^ 1u));
                     uint32_t w_self = 0xFFFFu, w_sib = 0xFFFFu;
                     if (node & 1u) {
                         if (!sib_present) { w_sib = wcount; wcount += 2; }
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
         c.n_batches[g] = n_batches;
     }
     if (flags) atomicOr(&c.flags, flags);
+#undef SQ
 }
 
 // ------------------------------------------------------------------ k_query
