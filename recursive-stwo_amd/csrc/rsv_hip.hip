@@ -37,12 +37,14 @@ struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
     void* ws_fixed = nullptr;  // per-proof records of the current batch
     size_t ws_fixed_bytes = 0;
+    void* ws_rows = nullptr;   // k_row_hash output
+    size_t ws_rows_bytes = 0;
     VerifyState* vs = nullptr;
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
@@ -90,7 +92,8 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming) != hipSuccess) {
         rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
     }
@@ -105,10 +108,12 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->ws) (void)hipFree(c->ws);
     if (c->ws_fixed) (void)hipFree(c->ws_fixed);
+    if (c->ws_rows) (void)hipFree(c->ws_rows);
     if (c->d_pi) (void)hipFree(c->d_pi);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -132,6 +137,7 @@ int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out,
     if (c->ws_bytes < 256) {
         if (c->ws) (void)hipFree(c->ws);
     if (c->ws_fixed) (void)hipFree(c->ws_fixed);
+    if (c->ws_rows) (void)hipFree(c->ws_rows);
         c->ws = nullptr; c->ws_bytes = 0;
         HIP_TRY(hipMalloc(&c->ws, 1 << 20));
         c->ws_bytes = 1 << 20;

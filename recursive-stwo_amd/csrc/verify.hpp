@@ -855,6 +855,44 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     if (flags) atomicOr(&c->flags, flags);
 }
 
+// --------------------------------------------------------------- k_row_hash
+// Column hashing of the trace trees does not depend on the transcript: queried_values lists one row of
+// column values per distinct queried node, in ascending node order, leaf level first.  The sponge over row r
+// (primitives/merkle/src/lib.rs:50-181) can therefore run UNDERNEATH the latency-bound transcript kernel
+// (side stream): one lane per (proof, tree, row) hashes leaf-level row r counted from the start of
+// queried_values and lower-level row r counted from its END (where that block begins depends on how many
+// leaves are distinct, which is only known once the queries are).  k_trace_merkle then just picks its rows.
+//   rowh[((p*4 + t)*2 + 0)*G + r] = leaf hash of leaf row r
+//   rowh[((p*4 + t)*2 + 1)*G + r] = column capacity digest of the r-th LAST lower-level row
+struct RowHashArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n, G;
+    const ProofMeta* metas;
+    uint32_t* rowh;  // [n][4][2][G][8]
+};
+
+__global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
+    const uint32_t G = a.G, per_block = 256 / G;
+    const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
+    const uint32_t p = blockIdx.x * per_block + grp;
+    const int t = blockIdx.y;
+    if (grp >= per_block || p >= a.n) return;
+    const ProofMeta& m = a.metas[p];
+    if (m.reason != R_OK || r >= m.nq) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+    const uint32_t A = m.A, B = m.B, M = m.M;
+    const uint32_t mx = (t == 3) ? M : umax(A, B);
+    const uint32_t nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+    const uint32_t nc_lower = (t == 3 || A == B) ? 0u : (A < B ? plonk_cols(t) : poseidon_cols(t));
+    const uint32_t* qv = w + m.qv_off[t];
+    const uint32_t qv_n = m.qv_n[t];
+    uint32_t* out = a.rowh + (((size_t)p * 4 + t) * 2) * G * 8;
+    if ((r + 1) * nc_leaf <= qv_n) store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity(qv + r * nc_leaf, nc_leaf)));
+    if (nc_lower && (r + 1) * nc_lower <= qv_n)
+        store_hash(out + ((size_t)G + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
+}
+
 // ----------------------------------------------------------- k_trace_merkle
 // SinglePathMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:315-354)
 // for the four commitment trees: blockIdx.y = tree, one lane per (proof, query).
@@ -868,6 +906,8 @@ struct MerkleArgs {
     const uint32_t* leafv;
     uint32_t maxInner;
     uint32_t Lc;  // cap level: levels below Lc are hashed by merkle_cap (0 = walk every path to the root)
+    const uint32_t* rowh;  // k_row_hash output, [proof][4][2][Grow][8]
+    uint32_t Grow;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -956,7 +996,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     const uint32_t gbase = grp * G;
     const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
     uint32_t M = 0, A = 0, B = 0, mx = 0, nc_leaf = 0, qv_n = 0, hw_n = 0, s_top = 0, nd_leaf = 0;
-    const uint32_t *qv = nullptr, *hw = nullptr;
+    const uint32_t *qv = nullptr, *hw = nullptr, *rows = nullptr;
     bool bad = false;
     Hash8 cur = zero8();
     uint32_t qj = 0;
@@ -972,9 +1012,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         s_top = lvl_s(h->lvl[mx + 1]);
         nd_leaf = lvl_nd(h->lvl[mx]);
         qj = a.ctxs[p].q[j];
-        uint32_t off = ent_rb(ent[mx * G + j]) * nc_leaf;
-        if (off + nc_leaf > qv_n) bad = true;
-        else cur = leaf_from_capacity(sponge_capacity(qv + off, nc_leaf));
+        rows = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
+        const uint32_t row = ent_rb(ent[mx * G + j]);
+        if ((row + 1) * nc_leaf > qv_n) bad = true;
+        else cur = load_hash(rows + (size_t)row * 8);
     }
     if (Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
@@ -1003,9 +1044,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
             const uint32_t pl_ = lvl - 1;  // parent level
             uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));
             if (nc) {
-                uint32_t off = nd_leaf * nc_leaf + ent_rb(ent[pl_ * G + j]) * nc;
-                if (off + nc > qv_n) bad = true;
-                else cur = combine_with_column(cur, sponge_capacity(qv + off, nc));
+                // lower-level rows were hashed counting from the end of queried_values
+                const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
+                const uint32_t off = nd_leaf * nc_leaf + row * nc;
+                if (off + nc > qv_n || nd_lower - 1 - row >= a.Grow) bad = true;
+                else cur = combine_with_column(cur, load_hash(rows + ((size_t)a.Grow + (nd_lower - 1 - row)) * 8));
             }
         }
     }
