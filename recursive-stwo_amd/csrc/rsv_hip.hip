@@ -37,7 +37,7 @@ struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
@@ -93,7 +93,9 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess) {
         rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
     }
@@ -109,6 +111,8 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_query) (void)hipEventDestroy(c->ev_query);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->ws) (void)hipFree(c->ws);
