@@ -171,9 +171,10 @@ __device__ __forceinline__ uint32_t canon(uint32_t t) { return min(t, t - P); }
 
 // x in C  ->  x^5 in L2
 __device__ __forceinline__ uint32_t pow5(uint32_t x) {
-    uint32_t c2 = canon(fold2(mul64(dbl32(x), x)));       // 2x^2 < 2^63; fold <= 2P-1
+    const uint32_t xx = dbl32(x);                         // 2x <= 2P, used by the first and the last product
+    uint32_t c2 = canon(fold2(mul64(xx, x)));             // 2x^2 < 2^63; fold <= 2P-1
     uint32_t c4 = canon(fold2(mul64(dbl32(c2), c2)));
-    return fold2(mul64(dbl32(c4), x));                    // hi <= P, lo>>1 <= P
+    return fold2(mul64(xx, c4));                          // 2x*c4: hi <= P, lo>>1 <= P
 }
 
 // Y = 2*M4*(x0..x3) for 32-bit inputs (any u32), exact in 64 bits.
