@@ -172,6 +172,23 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
                          size_t n, const rsv_pcs_config* cfg, const rsv_public_input* pi,
                          size_t n_pi, uint8_t* d_accept, uint8_t* d_reason);
 
+/* ---- SURVEY 8f.1 (next row): per-query authentication paths -----------------
+ * Emits, while verifying, the per-query Merkle paths of the four commitment trees in TRANSCRIPT query order —
+ * the data SinglePathMerkleProof::from_stwo_proof (components/hints/src/decommit.rs:44-183) derives on the host
+ * by re-hashing stwo's batched decommitment.  All n proofs must share one shape: n_queries (>= 4) and
+ * max_log = M (log size of the largest column) as declared by the caller, else RSV_E_SIZE.
+ *   d_sib  [n][4][n_queries][max_log][8]  sibling hash at the k-th level above the leaf of tree t at index k
+ *                                         (entries beyond the tree's depth are not written)
+ *   d_pos  [n][4][n_queries]              position of the query at the tree's leaf level
+ * Tree depths: max(lp, lq) + log_blowup for trees 0..2, M for tree 3.  accept/reason as in rsv_verify_batch_dev. */
+int rsv_trace_paths_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
+                        const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log,
+                        uint32_t* d_sib, uint32_t* d_pos, uint8_t* d_accept, uint8_t* d_reason);
+/* Same on host buffers (copied to `device` and back). */
+int rsv_trace_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+                    uint32_t n_queries, uint32_t max_log, uint32_t* sib, uint32_t* pos, uint8_t* accept,
+                    uint8_t* reason, int device);
+
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).
  * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */

@@ -758,6 +758,14 @@ static const node* find_node(const node* l, uint32_t n, uint32_t pos) {
  * cols_out[h] (if non-NULL) receives, for the distinct positions at layer h in
  * ascending order, a pointer to that node's column words. */
 typedef struct { uint32_t n; uint32_t pos[MAX_QUERIES]; const uint32_t* vals[MAX_QUERIES]; } layer_cols;
+/* every node hash known at a layer (computed nodes and witness siblings), for per-path extraction */
+typedef struct { uint32_t n[32]; node nodes[32][2 * MAX_QUERIES]; } tree_record;
+static void rec_add(tree_record* r, uint32_t layer, uint32_t pos, const m31* h) {
+    if (!r) return;
+    node* d = &r->nodes[layer][r->n[layer]++];
+    d->pos = pos; memcpy(d->h, h, 32);
+}
+static tree_record* g_record; /* set by rsvo_trace_paths around verify_trace_tree */
 
 static int verify_trace_tree(const uint32_t* queries_at_max, uint32_t nq, uint32_t maxlog,
                              const uint32_t* ncols_at, const uint32_t* values, uint64_t n_values,
@@ -773,6 +781,7 @@ static int verify_trace_tree(const uint32_t* queries_at_max, uint32_t nq, uint32
         if (vi + nc > n_values) return 0;
         cur[ncur].pos = pos[i];
         hash_node(NULL, NULL, values + vi, nc, cur[ncur].h);
+        rec_add(g_record, maxlog, pos[i], cur[ncur].h);
         if (cols_out) { cols_out[maxlog].pos[i] = pos[i]; cols_out[maxlog].vals[i] = values + vi; }
         vi += nc; ncur++;
     }
@@ -792,10 +801,12 @@ static int verify_trace_tree(const uint32_t* queries_at_max, uint32_t nq, uint32
             else {
                 if (hi >= dec->n_hash) return 0;
                 sh = dec->hash_witness + 8 * hi++;
+                rec_add(g_record, layer + 1, pos[i] ^ 1, sh);
             }
             nxt[nn].pos = parent;
             if (pos[i] & 1) hash_node(sh, self->h, c, nc, nxt[nn].h);
             else hash_node(self->h, sh, c, nc, nxt[nn].h);
+            rec_add(g_record, layer, parent, nxt[nn].h);
             if (cols_out && nc) { cols_out[layer].pos[nn] = parent; cols_out[layer].vals[nn] = c; }
             nn++;
         }
@@ -951,6 +962,9 @@ typedef struct {
     qm31 answers[3][MAX_QUERIES];
     qm31 last_value[MAX_QUERIES];
     uint32_t n_sizes;
+    /* optional: per-path extraction of the trace trees (rsvo_trace_paths) */
+    tree_record* records; /* [4] or NULL */
+    uint32_t qM[MAX_QUERIES], M, maxlog[4], nq;
 } query_probe;
 
 static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config* cfg,
@@ -984,9 +998,16 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
         else { ncols_at[M] = 8; maxlog = M; }
         uint32_t q[MAX_QUERIES];
         for (uint32_t j = 0; j < nq; j++) q[j] = qM[j] >> (M - maxlog);
-        if (!verify_trace_tree(q, nq, maxlog, ncols_at, v->queried[tr], v->n_queried[tr], &v->decommit[tr],
-                               v->commitments[tr], cols[tr]))
-            FAIL(RSV_R_MERKLE_T0 + tr);
+        if (probe->records) {
+            g_record = &probe->records[tr];
+            memset(g_record->n, 0, sizeof g_record->n);
+            probe->maxlog[tr] = maxlog; probe->M = M; probe->nq = nq;
+            memcpy(probe->qM, qM, 4 * nq);
+        }
+        int tree_ok = verify_trace_tree(q, nq, maxlog, ncols_at, v->queried[tr], v->n_queried[tr], &v->decommit[tr],
+                                        v->commitments[tr], cols[tr]);
+        g_record = NULL;
+        if (!tree_ok) FAIL(RSV_R_MERKLE_T0 + tr);
     }
     /* quotient groups by descending column log size: answer/src/lib.rs:294-315 */
     uint32_t sizes[3]; uint32_t n_sizes = 0;
@@ -1137,7 +1158,7 @@ int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, co
     if (n_pi && !pi) return RSV_E_NULL;
     for (size_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return RSV_E_SIZE;
     for (size_t i = 0; i < n_pi; i++) if (!canonical(pi[i].value, 4)) return RSV_E_RANGE;
-    query_probe* scratch = malloc(sizeof *scratch);
+    query_probe* scratch = calloc(1, sizeof *scratch);
     for (size_t i = 0; i < n; i++) {
         uint8_t r = verify_one(blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), cfg, pi, n_pi, scratch);
         accept[i] = r == RSV_R_OK;
@@ -1169,5 +1190,39 @@ int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* 
     rc = (int)o;
 done:
     free(pr); free(v);
+    return rc;
+}
+
+/* the per-query authentication paths SinglePathMerkleProof::from_stwo_proof
+ * (components/hints/src/decommit.rs:144-183) cherry-picks from the batched walk, transcript query order.
+ * sib layout [4][nq][M][8] (level k above the leaf at index k), pos [4][nq], depth4 [4]. */
+int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
+                     size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries) {
+    if (!proof || !sib || !pos || !depth4 || !n_queries) return RSV_E_NULL;
+    query_probe* pr = calloc(1, sizeof *pr);
+    pr->records = calloc(4, sizeof(tree_record));
+    int rc = RSV_OK;
+    uint8_t r = verify_one(proof, len, NULL, pi, n_pi, pr);
+    if (r != RSV_R_OK) { rc = RSV_E_SIZE; goto done; }
+    const uint32_t nq = pr->nq, M = pr->M;
+    if (cap < (size_t)4 * nq * M * 8) { rc = RSV_E_CAP; goto done; }
+    *n_queries = nq;
+    for (int t = 0; t < 4; t++) {
+        const tree_record* rec = &pr->records[t];
+        const uint32_t mx = pr->maxlog[t];
+        depth4[t] = mx;
+        for (uint32_t i = 0; i < nq; i++) {
+            uint32_t cur = pr->qM[i] >> (M - mx);
+            pos[t * nq + i] = cur;
+            for (uint32_t k = 0; k < mx; k++) {
+                const node* sn = find_node(rec->nodes[mx - k], rec->n[mx - k], cur ^ 1);
+                if (!sn) { rc = RSV_E_SIZE; goto done; }
+                memcpy(sib + (((size_t)t * nq + i) * M + k) * 8, sn->h, 32);
+                cur >>= 1;
+            }
+        }
+    }
+done:
+    free(pr->records); free(pr);
     return rc;
 }

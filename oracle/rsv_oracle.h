@@ -54,6 +54,11 @@ void rsvo_domain_point(uint32_t log_size, uint32_t q, uint32_t* xy);
 int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi,
                       uint32_t* out, size_t cap);
 
+/* per-query authentication paths of the four commitment trees (transcript query order):
+ * sib [4][n_queries][M][8] (k-th level above the leaf at index k), pos [4][n_queries], depth4 [4]. */
+int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
+                     size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,10 @@ def _load() -> ctypes.CDLL:
         "rsv_verify_batch_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PcsConfig),
                                                 ctypes.POINTER(PublicInput), sz, vp, vp]),
         "rsv_accept_bitmap_dev": (ctypes.c_int, [vp, vp, sz, vp, vp]),
+        "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+                                               ctypes.c_uint32, vp, vp, vp, vp]),
+        "rsv_trace_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+                                           ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
         "rsv_last_stage_times": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                                 ctypes.c_int]),
     }
@@ -98,7 +102,8 @@ lib = _load()
 EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_destroy", "rsv_ctx_synchronize",
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
-           "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times"]
+           "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
+           "rsv_trace_paths"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -232,6 +237,22 @@ def verify_batch(proofs: Sequence[bytes], inputs=STANDARD_INPUTS, cfg: Optional[
     return accept, reason
 
 
+def trace_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, inputs=STANDARD_INPUTS, device: int = 0):
+    """per-query authentication paths of the four commitment trees, transcript query order.
+    Returns (sib uint32[n,4,n_queries,max_log,8], pos uint32[n,4,n_queries], accept, reason)."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    sib = np.zeros((n, 4, n_queries, max_log, 8), np.uint32)
+    pos = np.zeros((n, 4, n_queries), np.uint32)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    _check(lib.rsv_trace_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, pi, len(list(inputs)),
+                               n_queries, max_log, sib.ctypes.data_as(_u32p), pos.ctypes.data_as(_u32p),
+                               accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_trace_paths")
+    return sib, pos, accept, reason
+
+
 class Context:
     """One HIP stream + reusable HBM workspace on one device (rsv_ctx).  Operates on torch tensors that
     already live on that device; nothing is copied through the host."""
@@ -271,6 +292,13 @@ class Context:
                                         ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
                                         d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
                "rsv_verify_batch_dev")
+
+    def trace_paths(self, d_blob, d_offsets, n: int, n_queries: int, max_log: int, d_sib, d_pos, d_accept,
+                    d_reason=None, inputs=STANDARD_INPUTS):
+        pi = make_inputs(inputs)
+        _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
+                                       n_queries, max_log, d_sib.data_ptr(), d_pos.data_ptr(), d_accept.data_ptr(),
+                                       d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
 
     def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):
         _check(lib.rsv_accept_bitmap_dev(self._h, d_accept.data_ptr(), n, d_bitmap.data_ptr(),

@@ -93,6 +93,7 @@ struct ProofCtx {
     uint32_t fri_alpha[MAX_INNER + 1][4];
     uint32_t raw_q[MAXQ];    // raw query words in transcript order
     uint32_t q[MAXQ];        // query positions at log M, ascending
+    uint8_t qperm[MAXQ];     // qperm[k] = transcript index of the k-th smallest query
     QBatch batch[3][2];      // per size group: batch 0 = OODS point, batch 1 = OODS - trace step
     uint32_t n_batches[3];
     uint32_t apow[N_APOW][4];  // -2u * after^k

@@ -472,6 +472,7 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
                                              uint32_t n, const ProofMeta* __restrict__ metas,
                                              ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
     __shared__ uint32_t sq[MAXQ][64];
+    __shared__ uint8_t sp[MAXQ][64];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const uint32_t p = pl.proof_of(slot);
@@ -487,10 +488,11 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
     for (uint32_t j = 0; j < nq; j++) {
         uint32_t v = c.raw_q[j] & ((1u << M) - 1u);
         uint32_t k = j;
-        while (k > 0 && SQ(k - 1) > v) { SQ(k) = SQ(k - 1); k--; }
+        while (k > 0 && SQ(k - 1) > v) { SQ(k) = SQ(k - 1); sp[k][threadIdx.x] = sp[k - 1][threadIdx.x]; k--; }
         SQ(k) = v;
+        sp[k][threadIdx.x] = (uint8_t)j;
     }
-    for (uint32_t j = 0; j < nq; j++) c.q[j] = SQ(j);
+    for (uint32_t j = 0; j < nq; j++) { c.q[j] = SQ(j); c.qperm[j] = sp[j][threadIdx.x]; }
     for (uint32_t j = 0; j + 1 < nq; j++)
         if (SQ(j) == SQ(j + 1)) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
     // column log sizes, descending
@@ -908,6 +910,11 @@ struct MerkleArgs {
     uint32_t Lc;  // cap level: levels below Lc are hashed by merkle_cap (0 = walk every path to the root)
     const uint32_t* rowh;  // k_row_hash output, [proof][4][2][Grow][8]
     uint32_t Grow;
+    // optional per-query authentication paths of the trace trees, transcript query order:
+    //   path_sib[((slot*4 + t)*G + i)*maxM + k]  = sibling hash at the k-th level above the leaf (8 words)
+    //   path_pos[(slot*4 + t)*G + i]              = position of query i at the tree's leaf level
+    uint32_t* path_sib;
+    uint32_t* path_pos;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -1040,6 +1047,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
                 else { sib = zero8(); bad = true; }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
+            if (a.path_sib) {
+                const uint32_t oi = a.ctxs[p].qperm[j];
+                store_hash(a.path_sib + ((((size_t)slot_ * 4 + t) * G + oi) * a.pl.maxM + (mx - lvl)) * 8, sib);
+                if (lvl == mx) a.path_pos[((size_t)slot_ * 4 + t) * G + oi] = qj >> (M - mx);
+            }
             cur = hash_tree_swap(cur, sib, odd);
             const uint32_t pl_ = lvl - 1;  // parent level
             uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));

@@ -43,6 +43,8 @@ lib.rsvo_qm31_mul.argtypes = [_u32p, _u32p, _u32p]
 lib.rsvo_qm31_inv.argtypes = [_u32p, _u32p]
 lib.rsvo_domain_point.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _u32p]
 
+lib.rsvo_trace_paths.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p, _u32p, _u32p]
+
 STANDARD_INPUTS = [(1, (1, 0, 0, 0)), (2, (0, 1, 0, 0)), (3, (0, 0, 1, 0))]
 
 
@@ -185,3 +187,19 @@ def tamper(proof: bytes, i: int, seed: int = 0xC0FFEE) -> bytes:
     off = 60 + splitmix64(seed, i) % (len(b) - 68)
     b[off] ^= 1
     return bytes(b)
+
+
+def trace_paths(proof: bytes, n_queries: int, max_log: int, inputs=STANDARD_INPUTS):
+    """-> (sib uint32[4, nq, M, 8], pos uint32[4, nq], depth uint32[4])."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    sib = np.zeros((4, n_queries, max_log, 8), np.uint32)
+    pos = np.zeros((4, n_queries), np.uint32)
+    depth = np.zeros(4, np.uint32)
+    nq = np.zeros(1, np.uint32)
+    pi = make_inputs(inputs)
+    rc = lib.rsvo_trace_paths(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), sib.ctypes.data_as(_u32p),
+                              sib.size, pos.ctypes.data_as(_u32p), depth.ctypes.data_as(_u32p), nq.ctypes.data_as(_u32p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_trace_paths -> {rc}")
+    assert int(nq[0]) == n_queries
+    return sib, pos, depth

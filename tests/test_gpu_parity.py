@@ -280,3 +280,25 @@ def test_cap_disabled_matches_cap_enabled(rsv, monkeypatch):
     a1, r1 = rsv.verify_batch(batch)
     assert a0.tolist() == a1.tolist() and r0.tolist() == r1.tolist()
     assert a1[-3:].tolist() == [1, 1, 1]
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])
+def test_trace_paths_match_oracle(rsv, manifest, name):
+    """per-query authentication paths (transcript order) emitted by the GPU == oracle's."""
+    entry = next(e for e in manifest if e["file"] == name)
+    proof = read_proof(name)
+    nq = entry["n_queries"]
+    M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
+    inputs = entry_inputs(entry)
+    osib, opos, depth = ob.trace_paths(proof, nq, M, inputs)
+    sib, pos, acc, reason = rsv.trace_paths([proof, proof], nq, M, inputs)
+    assert acc.tolist() == [1, 1] and reason.tolist() == [0, 0]
+    for k in range(2):
+        assert np.array_equal(pos[k], opos)
+        for t in range(4):
+            d = int(depth[t])
+            assert np.array_equal(sib[k, t, :, :d, :], osib[t, :, :d, :]), (k, t)
+    # shape mismatch is an API error, not a verdict
+    with pytest.raises(rsv.RsvError) as e:
+        rsv.trace_paths([proof], nq, M + 1, inputs)
+    assert e.value.code == -2

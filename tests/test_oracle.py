@@ -158,3 +158,40 @@ def test_domain_points_on_circle():
         x0, y0 = ob.domain_point(log, 6)
         x1, y1 = ob.domain_point(log, 7)
         assert x0 == x1 and (y0 + y1) % P == 0
+
+
+def test_trace_paths_verify_against_commitments():
+    """the per-query paths cherry-picked from the batched walk each recompute the committed root
+    (SinglePathMerkleProof::verify, components/hints/src/decommit.rs:22-42)."""
+    import struct
+    for name, inputs in (("small_proof.bin", [(1, (1, 0, 0, 0))]), ("recursive_proof_16_15.bin", ob.STANDARD_INPUTS)):
+        proof = read_proof(name)
+        t = ob.transcript_raw(proof)
+        nq, M = int(t[2]), int(t[3])
+        sib, pos, depth = ob.trace_paths(proof, nq, M, inputs)
+        words = np.frombuffer(proof, dtype=np.uint32)
+        lp, lq, blowup = int(words[0]), int(words[1]), int(words[11])
+        A, B = lp + blowup, lq + blowup
+        assert depth.tolist() == [max(A, B)] * 3 + [M]
+        raw = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + nq] & ((1 << M) - 1)
+        for tr in range(4):
+            assert pos[tr].tolist() == (raw >> (M - int(depth[tr]))).tolist()
+        # tree 3 (composition, 8 columns at the leaves only): rebuild its roots with the generic path hasher
+        d = int(depth[3])
+        # columns come from queried_values[3]: one row of 8 words per query, in ascending query order;
+        # locate it by walking the bincode prefixes (decommitments start at word 895, SURVEY App. A)
+        order = np.argsort(raw, kind="stable")
+        pos_w = 895 + 2
+        for _ in range(4):
+            nh = int(words[pos_w]); pos_w += 2 + 8 * nh + 2
+        pos_w += 2
+        qvs = []
+        for _ in range(4):
+            nv = int(words[pos_w]); qvs.append(words[pos_w + 2:pos_w + 2 + nv]); pos_w += 2 + nv
+        rows = qvs[3].reshape(-1, 8)
+        cols = np.zeros((nq, 8), np.uint32)
+        cols[order] = rows
+        n_cols_at = [0] * d + [8]
+        roots = ob.merkle_path_root(pos[3], sib[3][:, :d, :], cols, n_cols_at)
+        commitment3 = words[17 + 24:17 + 32]
+        assert all(r.tolist() == commitment3.tolist() for r in roots)
