@@ -1,0 +1,64 @@
+"""bench.py contract: one JSON line with the fields the driver reads; the N>1 path is rehearsed with two
+ranks on one GPU (RSV_BENCH_REHEARSAL=1: bitmap exchange over gloo, since RCCL refuses two ranks per device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _check_line(out, n_gpus):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    return d
+
+
+def test_bench_refuses_without_gpu():
+    import rsvload
+    if rsvload.load_package().device_count() > 0:
+        pytest.skip("a HIP device is present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--proofs", "64"], capture_output=True, text=True)
+    assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--proofs", "2048", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "64", "--perm-log2", "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check_line(out.stdout, 1)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, RSV_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--proofs", "2048",
+           "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _check_line(out.stdout, 2)
+    assert d["config"]["parallelism"] == "shard2"
