@@ -869,17 +869,20 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
 struct RowHashArgs {
     const uint8_t* blob;
     const uint64_t* offsets;
-    uint32_t n, G;
+    uint32_t n, G;         // slots in this launch, lanes per proof (= n_queries of the bucket)
     const ProofMeta* metas;
-    uint32_t* rowh;  // [n][4][2][G][8]
+    uint32_t* rowh;        // [proof][4][2][Grow][8]
+    uint32_t Grow;         // row stride of rowh (max n_queries of the batch)
+    const uint32_t* ids;   // slot -> proof (nullptr: identity)
 };
 
 __global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
     const uint32_t G = a.G, per_block = 256 / G;
     const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
-    const uint32_t p = blockIdx.x * per_block + grp;
+    const uint32_t slot = blockIdx.x * per_block + grp;
     const int t = blockIdx.y;
-    if (grp >= per_block || p >= a.n) return;
+    if (grp >= per_block || slot >= a.n) return;
+    const uint32_t p = a.ids ? a.ids[slot] : slot;
     const ProofMeta& m = a.metas[p];
     if (m.reason != R_OK || r >= m.nq) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
@@ -889,10 +892,10 @@ __global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
     const uint32_t nc_lower = (t == 3 || A == B) ? 0u : (A < B ? plonk_cols(t) : poseidon_cols(t));
     const uint32_t* qv = w + m.qv_off[t];
     const uint32_t qv_n = m.qv_n[t];
-    uint32_t* out = a.rowh + (((size_t)p * 4 + t) * 2) * G * 8;
+    uint32_t* out = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
     if ((r + 1) * nc_leaf <= qv_n) store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity(qv + r * nc_leaf, nc_leaf)));
     if (nc_lower && (r + 1) * nc_lower <= qv_n)
-        store_hash(out + ((size_t)G + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
+        store_hash(out + ((size_t)a.Grow + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
 }
 
 // ----------------------------------------------------------- k_trace_merkle
