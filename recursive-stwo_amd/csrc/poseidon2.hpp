@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t pow5_ref(uint32_t x) {
     return m_mul(m_sqr(x2), x);
 }
 
-// M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] in 8 additions, 2 doublings, 2 x4.
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] (Poseidon2 paper, 5.1) in 8 additions, 2 doublings, 2 x4.
 __device__ __forceinline__ void mds4_ref(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
     uint32_t t0 = m_add(x0, x1), t1 = m_add(x2, x3);
     uint32_t t2 = m_add(m_dbl(x1), t1), t3 = m_add(m_dbl(x3), t0);
@@ -193,7 +193,7 @@ __device__ __forceinline__ void mds4_2x(uint32_t k2, uint32_t k4, uint32_t x0, u
 }
 
 // V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i]   (+ 2*rc[i] for i < n_rc), inputs any u32 (< 2^32):
-// every V[i] < 2 * 35 * 2^32 + 2^32 < 2^39.
+// the matrix rows sum to at most 16 * 5 = 80, so every V[i] < 2 * 80 * 2^32 + 2^33 < 2^41.
 __device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, uint32_t v2, const uint32_t* s, uint64_t* V,
                                          const uint32_t* rc, int n_rc) {
 #pragma unroll
@@ -220,7 +220,7 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));       // fold <= P + 71 <= 2P
+        for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));       // fold <= P + 161 <= 2P
         if (r < 3) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
         else mds16_2x(k2, k4, v2, s, V, RC_PARTIAL, 1);                                  // only lane 0 gets a constant
     }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
         if (r < 7) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
         else mds16_2x(k2, k4, v2, s, V, nullptr, 0);
     }
-    // canonical output: fold <= P + 70, so one conditional subtract lands in [0, P); P itself maps to 0
+    // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         uint32_t t = fold2(V[i]);

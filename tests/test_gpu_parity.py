@@ -302,3 +302,17 @@ def test_trace_paths_match_oracle(rsv, manifest, name):
     with pytest.raises(rsv.RsvError) as e:
         rsv.trace_paths([proof], nq, M + 1, inputs)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("mode", ["row", "lane"])
+def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+    """Both transcript kernels (one proof per 16-lane DPP row / one proof per lane) against the oracle."""
+    monkeypatch.setenv("RSV_TRANSCRIPT", mode)
+    for entry in manifest:
+        proof = read_proof(entry["file"])
+        assert rsv.transcript(proof) == rsv._parse_transcript(ob.transcript_raw(proof)), (mode, entry["file"])
+    proof = read_proof("recursive_proof_16_15.bin")
+    batch = [ob.tamper(proof, i) for i in range(40)] + [proof, read_proof("level1-5.bin"), read_proof("level13-1.bin")]
+    acc, reason = rsv.verify_batch(batch)
+    oacc, oreason = ob.verify_batch(batch)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
