@@ -189,6 +189,21 @@ int rsv_trace_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, cons
                     uint32_t n_queries, uint32_t max_log, uint32_t* sib, uint32_t* pos, uint8_t* accept,
                     uint8_t* reason, int device);
 
+/* Same for the FRI trees: the per-query pair paths SinglePairMerkleProof::from_stwo_proof
+ * (components/hints/src/folding.rs:93-287) derives on the host.  Tree s = 0 is the first layer (leaf level
+ * M = max_log, one QM31 column at each distinct column log size), s = 1 + i inner layer i (leaf level M - 1 - i).
+ * The batch must share (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE.
+ *   d_sib  [n][1 + n_inner][n_queries][max_log][8]  sibling_hashes[k], k = 0..depth-2: at level depth-1-k the
+ *                                                   sibling's hash, or — where that level carries a column —
+ *                                                   the hash of the sibling's children
+ *   d_cols [n][1 + n_inner][n_queries][3][8]        c-th column level from the top: self value | sibling value */
+int rsv_fri_paths_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
+                      const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log, uint32_t n_inner,
+                      uint32_t* d_sib, uint32_t* d_cols, uint8_t* d_accept, uint8_t* d_reason);
+int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+                  uint32_t n_queries, uint32_t max_log, uint32_t n_inner, uint32_t* sib, uint32_t* cols, uint8_t* accept,
+                  uint8_t* reason, int device);
+
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).
  * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */

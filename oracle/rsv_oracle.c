@@ -822,9 +822,20 @@ static int verify_trace_tree(const uint32_t* queries_at_max, uint32_t nq, uint32
  * (components/hints/src/folding.rs:93-212).  has_data[l] marks layers carrying one
  * QM31 column; values lists, per data layer (descending), for the sorted
  * positions (queries and their siblings) 4 words each. */
+/* optional recording for rsvo_fri_paths: every node hash known at a level, the column value of every data-level
+ * candidate, and for data levels below the leaves the hash of the candidate's children (hash_node(children, [])) */
+typedef struct {
+    uint32_t n[32], nc[32];
+    node nodes[32][8 * MAX_QUERIES];
+    struct { uint32_t pos; m31 val[4]; m31 kids[8]; } cand[32][2 * MAX_QUERIES];
+} pair_record;
+static pair_record* g_pair_record;
+
 static int verify_pair_tree(const uint32_t* leaf_queries, uint32_t nq, uint32_t maxlog,
                             const uint8_t* has_data, const uint32_t* values, uint64_t n_values,
                             const decommit_view* dec, const uint32_t* root) {
+    pair_record* rec = g_pair_record;
+    if (rec) { memset(rec->n, 0, sizeof rec->n); memset(rec->nc, 0, sizeof rec->nc); }
     uint32_t q[MAX_QUERIES];
     memcpy(q, leaf_queries, 4 * nq);
     uint32_t n = nq;
@@ -867,8 +878,17 @@ static int verify_pair_tree(const uint32_t* leaf_queries, uint32_t nq, uint32_t 
                     prev[nprev].pos = (cand[i] << 1) + 1; memcpy(prev[nprev].h, rh, 32); nprev++;
                 }
                 hash_node(lh, rh, val, val ? 4 : 0, cur[ncur].h);
+                if (rec && val) hash_node(lh, rh, NULL, 0, rec->cand[l][rec->nc[l]].kids);
+            }
+            if (rec && val) {
+                rec->cand[l][rec->nc[l]].pos = cand[i];
+                memcpy(rec->cand[l][rec->nc[l]].val, val, 16);
+                rec->nc[l]++;
             }
             ncur++;
+        }
+        if (rec && l < maxlog) { /* children level l+1 is complete now (witness children were appended to prev) */
+            memcpy(rec->nodes[l + 1], prev, sizeof(node) * nprev); rec->n[l + 1] = nprev;
         }
         memcpy(prev, cur, sizeof(node) * ncur); nprev = ncur;
         for (uint32_t i = 0; i < n; i++) q[i] >>= 1;
@@ -965,6 +985,8 @@ typedef struct {
     /* optional: per-path extraction of the trace trees (rsvo_trace_paths) */
     tree_record* records; /* [4] or NULL */
     uint32_t qM[MAX_QUERIES], M, maxlog[4], nq;
+    pair_record* pair_records; /* [1 + n_inner] or NULL */
+    uint32_t n_inner;
 } query_probe;
 
 static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config* cfg,
@@ -1089,8 +1111,10 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
             }
         }
         if (wi != v->first.n_witness) FAIL(RSV_R_FRI_FIRST); /* folding.rs:367 */
-        if (!verify_pair_tree(qM, nq, M, has_data, flat, nflat, &v->first.decommit, v->first.commitment))
-            FAIL(RSV_R_FRI_FIRST);
+        if (probe->pair_records) { g_pair_record = &probe->pair_records[0]; probe->n_inner = v->n_inner; probe->M = M; probe->nq = nq; memcpy(probe->qM, qM, 4 * nq); }
+        int first_ok = verify_pair_tree(qM, nq, M, has_data, flat, nflat, &v->first.decommit, v->first.commitment);
+        g_pair_record = NULL;
+        if (!first_ok) FAIL(RSV_R_FRI_FIRST);
     }
     /* FRI inner layers: components/hints/src/folding.rs:460-566, recursive/folding/src/lib.rs:120-192 */
     qm31 folded[MAX_QUERIES];
@@ -1123,8 +1147,10 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
         if (wi != L->n_witness) FAIL(RSV_R_FRI_INNER); /* folding.rs:558 */
         uint8_t has_data[32] = {0};
         has_data[l] = 1;
-        if (!verify_pair_tree(pq, nq, l, has_data, flat, nflat, &L->decommit, L->commitment))
-            FAIL(RSV_R_FRI_INNER);
+        if (probe->pair_records) g_pair_record = &probe->pair_records[1 + i];
+        int inner_ok = verify_pair_tree(pq, nq, l, has_data, flat, nflat, &L->decommit, L->commitment);
+        g_pair_record = NULL;
+        if (!inner_ok) FAIL(RSV_R_FRI_INNER);
         for (uint32_t j = 0; j < nq; j++) {
             qm31 self = folded[j], sib = Q_ZERO;
             for (uint32_t k = 0; k < np; k++) if (ps[k] == (pq[j] ^ 1)) sib = vals[k];
@@ -1224,5 +1250,53 @@ int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* p
     }
 done:
     free(pr->records); free(pr);
+    return rc;
+}
+
+/* SURVEY 8f.1, pair trees: what SinglePairMerkleProof::from_stwo_proof (components/hints/src/folding.rs:214-287)
+ * cherry-picks, transcript query order.  Tree s = 0 is the FRI first layer (leaf level M), s = 1 + i inner layer i
+ * (leaf level M - 1 - i).  For the tree of depth d:
+ *   sib  [(s*nq + q)*M + k]      k = 0..d-2: sibling_hashes[k], i.e. at level d-1-k the sibling's hash, or — where
+ *                                that level carries a column — the hash of the sibling's children
+ *   cols [((s*nq + q)*3 + c)*8]  c-th data level from the top (first layer: up to 3, inner: 1): self value | sibling value */
+int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
+                   size_t cap, uint32_t* cols, uint32_t* n_trees, uint32_t* n_queries) {
+    if (!proof || !sib || !cols || !n_trees || !n_queries) return RSV_E_NULL;
+    query_probe* pr = calloc(1, sizeof *pr);
+    pr->pair_records = calloc(1 + MAX_LAYERS, sizeof(pair_record));
+    int rc = RSV_OK;
+    uint8_t r = verify_one(proof, len, NULL, pi, n_pi, pr);
+    if (r != RSV_R_OK) { rc = RSV_E_SIZE; goto done; }
+    const uint32_t nq = pr->nq, M = pr->M, nt = 1 + pr->n_inner;
+    if (cap < (size_t)nt * nq * M * 8) { rc = RSV_E_CAP; goto done; }
+    *n_trees = nt; *n_queries = nq;
+    for (uint32_t s2 = 0; s2 < nt; s2++) {
+        const pair_record* rec = &pr->pair_records[s2];
+        const uint32_t d = s2 == 0 ? M : M - s2;
+        for (uint32_t i = 0; i < nq; i++) {
+            uint32_t cur = pr->qM[i] >> (M - d), c = 0, k = 0;
+            for (uint32_t l = d; l >= 1; l--) {
+                if (rec->nc[l]) {
+                    const m31 *sv = NULL, *bv = NULL, *kids = NULL;
+                    for (uint32_t t = 0; t < rec->nc[l]; t++) {
+                        if (rec->cand[l][t].pos == cur) sv = rec->cand[l][t].val;
+                        if (rec->cand[l][t].pos == (cur ^ 1)) { bv = rec->cand[l][t].val; kids = rec->cand[l][t].kids; }
+                    }
+                    if (!sv || !bv) { rc = RSV_E_SIZE; goto done; }
+                    uint32_t* o = cols + (((size_t)s2 * nq + i) * 3 + c) * 8;
+                    memcpy(o, sv, 16); memcpy(o + 4, bv, 16);
+                    c++;
+                    if (l != d) { memcpy(sib + (((size_t)s2 * nq + i) * M + k) * 8, kids, 32); k++; }
+                } else {
+                    const node* sn = find_node(rec->nodes[l], rec->n[l], cur ^ 1);
+                    if (!sn) { rc = RSV_E_SIZE; goto done; }
+                    memcpy(sib + (((size_t)s2 * nq + i) * M + k) * 8, sn->h, 32); k++;
+                }
+                cur >>= 1;
+            }
+        }
+    }
+done:
+    free(pr->pair_records); free(pr);
     return rc;
 }

@@ -59,6 +59,10 @@ int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* 
 int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
                      size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries);
 
+/* SURVEY 8f.1, pair trees (layout: see rsv_oracle.c). */
+int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
+                   size_t cap, uint32_t* cols, uint32_t* n_trees, uint32_t* n_queries);
+
 #ifdef __cplusplus
 }
 #endif

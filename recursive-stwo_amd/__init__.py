@@ -86,6 +86,10 @@ def _load() -> ctypes.CDLL:
         "rsv_accept_bitmap_dev": (ctypes.c_int, [vp, vp, sz, vp, vp]),
         "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
+        "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+                                             ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp]),
+        "rsv_fri_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
         "rsv_trace_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                            ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
         "rsv_last_stage_times": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
@@ -103,7 +107,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
-           "rsv_trace_paths"]
+           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -251,6 +255,22 @@ def trace_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, inputs=ST
                                n_queries, max_log, sib.ctypes.data_as(_u32p), pos.ctypes.data_as(_u32p),
                                accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_trace_paths")
     return sib, pos, accept, reason
+
+
+def fri_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
+    """per-query pair paths of the FRI trees.  Returns (sib uint32[n,1+n_inner,nq,max_log,8],
+    cols uint32[n,1+n_inner,nq,3,8], accept, reason)."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    sib = np.zeros((n, 1 + n_inner, n_queries, max_log, 8), np.uint32)
+    cols = np.zeros((n, 1 + n_inner, n_queries, 3, 8), np.uint32)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    _check(lib.rsv_fri_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, pi, len(list(inputs)), n_queries,
+                             max_log, n_inner, sib.ctypes.data_as(_u32p), cols.ctypes.data_as(_u32p),
+                             accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_fri_paths")
+    return sib, cols, accept, reason
 
 
 class Context:

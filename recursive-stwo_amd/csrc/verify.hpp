@@ -1007,6 +1007,11 @@ struct MerkleArgs {
     //   path_pos[(slot*4 + t)*G + i]              = position of query i at the tree's leaf level
     uint32_t* path_sib;
     uint32_t* path_pos;
+    // optional per-query pair paths of the FRI trees (SinglePairMerkleProof, components/hints/src/folding.rs:214-287):
+    //   pair_sib [(((slot*(1+maxInner) + s)*G + i)*maxM + k]  sibling_hashes[k] of tree s (0 = first layer), 8 words
+    //   pair_cols[(((slot*(1+maxInner) + s)*G + i)*3 + c]     c-th data level from the top: self | sibling value, 8 words
+    uint32_t* pair_sib;
+    uint32_t* pair_cols;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -1175,6 +1180,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     __shared__ uint32_t xch[2][BLOCK][8];
+    __shared__ uint32_t xch2[BLOCK][8];  // path emission only: pre-column node hashes at data levels
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
@@ -1191,6 +1197,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     const FriLayerRef* L = nullptr;
     uint32_t M = 0, top = 0, qj = 0, s_top = 0, dslot = 0;
     bool bad = false, have_sib = false;
+    uint32_t* psib = nullptr;
     Hash8 cur = zero8(), sibh = zero8();
     if (live) {
         w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
@@ -1209,6 +1216,17 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
         sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
         have_sib = true;
         dslot = 0;
+        if (a.pair_sib) {
+            const uint32_t oi = c->qperm[j];
+            const size_t row = ((size_t)slot_ * (1 + a.maxInner) + slot) * G + oi;
+            psib = a.pair_sib + row * a.pl.maxM * 8;
+            uint32_t* pc = a.pair_cols + row * 3 * 8;
+            const uint32_t nlev = slot == 0 ? c->n_sizes : 1u;
+            for (uint32_t g = 0; g < nlev; g++) {
+                const uint32_t* src = leafv + ((size_t)(slot == 0 ? g : 2 + slot) * G + j) * 8;
+                for (int k = 0; k < 8; k++) pc[g * 8 + k] = src[k];
+            }
+        }
     }
     if (Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
@@ -1242,12 +1260,15 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
                 }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
+            // sibling_hashes[top-1-lvl]: the sibling at a level without a column (data levels: stored in phase B)
+            if (psib && !have_sib) store_hash(psib + (size_t)(top - 1 - lvl) * 8, sibh);
             cur = hash_tree_swap(cur, sibh, odd);
             have_sib = false;
         }
         // phase B: data level of the first-layer tree: fold in the column and build the sibling node
         if (on && dg >= 0) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
+            if (a.pair_sib) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
             cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
             store_hash(xch[1][threadIdx.x], cur);
         }
@@ -1257,10 +1278,13 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
             uint32_t w_sib = fl[dslot * G + j] >> 16;
             if (w_sib == 0xFFFFu) {
                 uint32_t e = ent[pl_ * G + j];
-                if (ent_sib(e) != 0xFFu) sibh = load_hash(xch[1][gbase + ent_sib(e)]);
-                else bad = true;
+                if (ent_sib(e) != 0xFFu) {
+                    sibh = load_hash(xch[1][gbase + ent_sib(e)]);
+                    if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, load_hash(xch2[gbase + ent_sib(e)]));
+                } else bad = true;
             } else if (w_sib + 1 < L->hash_n) {
                 Hash8 sn = hash_tree(load_hash(w + L->hash_off + 8 * w_sib), load_hash(w + L->hash_off + 8 * (w_sib + 1)));
+                if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, sn);
                 sibh = combine_with_column(sn, sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
             } else bad = true;
             have_sib = true;

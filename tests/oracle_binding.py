@@ -45,6 +45,8 @@ lib.rsvo_domain_point.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _u32p]
 
 lib.rsvo_trace_paths.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p, _u32p, _u32p]
 
+lib.rsvo_fri_paths.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p, _u32p, _u32p]
+
 STANDARD_INPUTS = [(1, (1, 0, 0, 0)), (2, (0, 1, 0, 0)), (3, (0, 0, 1, 0))]
 
 
@@ -203,3 +205,46 @@ def trace_paths(proof: bytes, n_queries: int, max_log: int, inputs=STANDARD_INPU
         raise RuntimeError(f"rsvo_trace_paths -> {rc}")
     assert int(nq[0]) == n_queries
     return sib, pos, depth
+
+
+def fri_paths(proof: bytes, n_queries: int, max_log: int, n_trees: int, inputs=STANDARD_INPUTS):
+    """-> (sib uint32[n_trees, nq, M, 8], cols uint32[n_trees, nq, 3, 8])."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    sib = np.zeros((n_trees, n_queries, max_log, 8), np.uint32)
+    cols = np.zeros((n_trees, n_queries, 3, 8), np.uint32)
+    nt = np.zeros(1, np.uint32)
+    nq = np.zeros(1, np.uint32)
+    pi = make_inputs(inputs)
+    rc = lib.rsvo_fri_paths(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), sib.ctypes.data_as(_u32p), sib.size,
+                            cols.ctypes.data_as(_u32p), nt.ctypes.data_as(_u32p), nq.ctypes.data_as(_u32p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_fri_paths -> {rc}")
+    assert int(nt[0]) == n_trees and int(nq[0]) == n_queries
+    return sib, cols
+
+
+def proof_layout(proof: bytes):
+    """Word offsets of the variable part of a proof: FRI layer commitments etc."""
+    w = np.frombuffer(proof, dtype=np.uint32)
+    pos = 895 + 2
+    for _ in range(4):
+        nh = int(w[pos]); pos += 2 + 8 * nh + 2
+    pos += 2
+    for _ in range(4):
+        nv = int(w[pos]); pos += 2 + nv
+    pos += 2  # proof-of-work nonce
+    layers = []
+
+    def layer(pos):
+        nw = int(w[pos]); pos += 2 + 4 * nw
+        nh = int(w[pos]); pos += 2 + 8 * nh + 2
+        return pos + 8, w[pos:pos + 8].copy()
+
+    pos, c0 = layer(pos)
+    layers.append(c0)
+    n_inner = int(w[pos]); pos += 2
+    for _ in range(n_inner):
+        pos, ci = layer(pos)
+        layers.append(ci)
+    return {"lp": int(w[0]), "lq": int(w[1]), "blowup": int(w[11]), "log_last": int(w[12]), "nq": int(w[13]),
+            "fri_commitments": layers, "n_inner": n_inner}

@@ -316,3 +316,22 @@ def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
     acc, reason = rsv.verify_batch(batch)
     oacc, oreason = ob.verify_batch(batch)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level13-1.bin"])
+def test_fri_paths_match_oracle(rsv, manifest, name):
+    """per-query pair paths of every FRI tree (transcript order) emitted by the GPU == oracle's."""
+    entry = next(e for e in manifest if e["file"] == name)
+    proof = read_proof(name)
+    lay = ob.proof_layout(proof)
+    nq, n_inner = entry["n_queries"], lay["n_inner"]
+    M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
+    inputs = entry_inputs(entry)
+    osib, ocols = ob.fri_paths(proof, nq, M, 1 + n_inner, inputs)
+    sib, cols, acc, reason = rsv.fri_paths([proof, proof], nq, M, n_inner, inputs)
+    assert acc.tolist() == [1, 1] and reason.tolist() == [0, 0]
+    for k in range(2):
+        assert np.array_equal(cols[k], ocols)
+        for s2 in range(1 + n_inner):
+            d = M if s2 == 0 else M - s2
+            assert np.array_equal(sib[k, s2, :, :d - 1, :], osib[s2, :, :d - 1, :]), (k, s2)

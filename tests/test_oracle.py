@@ -195,3 +195,47 @@ def test_trace_paths_verify_against_commitments():
         roots = ob.merkle_path_root(pos[3], sib[3][:, :d, :], cols, n_cols_at)
         commitment3 = words[17 + 24:17 + 32]
         assert all(r.tolist() == commitment3.tolist() for r in roots)
+
+
+def _pair_path_root(query, depth, data_levels, sib, cols):
+    """SinglePairMerkleProof::verify (components/hints/src/folding.rs:33-91) with the oracle's hasher."""
+    z8 = np.zeros(8, np.uint32)
+    def colcap(v4):
+        return ob.poseidon2_permute(np.concatenate([v4, np.zeros(4, np.uint32), z8]))[0][8:]
+    def leaf(v4):
+        return ob.hash_node(None, v4)[0]
+    c = 0
+    self_h, sib_h = leaf(cols[c][:4]), leaf(cols[c][4:])
+    c += 1
+    for i in range(depth):
+        h = depth - i - 1
+        l, r = (self_h, sib_h) if ((query >> i) & 1) == 0 else (sib_h, self_h)
+        if h not in data_levels:
+            self_h = ob.hash_node((l, r), np.zeros((1, 0)))[0]
+            if i != depth - 1:
+                sib_h = sib[i]
+        else:
+            self_h = ob.hash_node((l, r), cols[c][:4])[0]
+            sib_h = ob.poseidon2_permute(np.concatenate([sib[i], colcap(cols[c][4:])]))[0][:8]
+            c += 1
+    return self_h
+
+
+def test_fri_paths_verify_against_commitments():
+    """per-query pair paths of every FRI tree recompute the layer commitments."""
+    for name, inputs in (("small_proof.bin", [(1, (1, 0, 0, 0))]), ("recursive_proof_16_15.bin", ob.STANDARD_INPUTS)):
+        proof = read_proof(name)
+        lay = ob.proof_layout(proof)
+        t = ob.transcript_raw(proof)
+        nq, M = int(t[2]), int(t[3])
+        nt = 1 + lay["n_inner"]
+        sib, cols = ob.fri_paths(proof, nq, M, nt, inputs)
+        raw = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + nq] & ((1 << M) - 1)
+        A, B = lay["lp"] + lay["blowup"], lay["lq"] + lay["blowup"]
+        for s2 in range(nt):
+            depth = M if s2 == 0 else M - s2
+            data_levels = {M, A, B} if s2 == 0 else {depth}
+            for q in (0, nq // 2, nq - 1):
+                query = int(raw[q]) >> (M - depth)
+                root = _pair_path_root(query, depth, data_levels, sib[s2, q], cols[s2, q])
+                assert root.tolist() == lay["fri_commitments"][s2].tolist(), (name, s2, q)
