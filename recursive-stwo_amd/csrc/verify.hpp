@@ -568,7 +568,6 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
     const ProofMeta& m = metas[p];
     if (m.reason != R_OK) return;
     ProofCtx& c = ctxs[p];
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     const uint32_t nq = m.nq, M = m.M, A = m.A, B = m.B, G = pl.G;
     uint32_t flags = 0;
     // query positions (primitives/query/src/lib.rs:19-38), sorted ascending.  The sorted list is walked
@@ -679,6 +678,27 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
         h.wf[0] = (uint16_t)wcount;
         h.wf_total = (uint16_t)umin(wcount, 0xFFFFu);
     }
+    if (flags) atomicOr(&c.flags, flags);
+#undef SQ
+}
+
+// ------------------------------------------------------------------ k_qconst
+// One lane per proof: the query-independent constants of the DEEP quotients — alpha powers and, per column
+// log size and sample point, the summed line coefficients.  Needs only the transcript, so it runs on the side
+// stream next to k_plan (whose tables need only the query positions).
+__global__ __launch_bounds__(64) void k_qconst(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                               uint32_t n, const ProofMeta* __restrict__ metas,
+                                               ProofCtx* __restrict__ ctxs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const uint32_t M = m.M, A = m.A, B = m.B;
+    // column log sizes, descending (the same list k_plan stores in ProofCtx::sizes)
+    uint32_t sizes[3] = {M, A == B ? A : umax(A, B), A == B ? 0u : umin(A, B)};
+    const uint32_t n_sizes = A == B ? 2u : 3u;
     // quotient constants: alpha_k = -2u * after^k (data_structures.rs:162-189)
     QM31 after = ldq(c.after);
     {
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
     }
     QM31 ox = ldq(c.oods_x), oy = ldq(c.oods_y);
     for (uint32_t g = 0; g < n_sizes; g++) {
-        uint32_t l = c.sizes[g];
+        uint32_t l = sizes[g];
         // batch 0: OODS point; batch 1: OODS - g_{component log size} (answer/src/lib.rs:62-72)
         uint32_t comp_log = (l == A) ? m.lp : m.lq;
         CPoint step = cp_gen_mul(1u << (31u - comp_log));
@@ -725,8 +745,6 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
         }
         c.n_batches[g] = n_batches;
     }
-    if (flags) atomicOr(&c.flags, flags);
-#undef SQ
 }
 
 // ------------------------------------------------------------------ k_query
@@ -1100,7 +1118,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     const uint32_t gbase = grp * G;
     const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
     uint32_t M = 0, A = 0, B = 0, mx = 0, nc_leaf = 0, qv_n = 0, hw_n = 0, s_top = 0, nd_leaf = 0;
-    const uint32_t *qv = nullptr, *hw = nullptr, *rows = nullptr;
+    const uint32_t *hw = nullptr, *rows = nullptr;
     bool bad = false;
     Hash8 cur = zero8();
     uint32_t qj = 0;
@@ -1111,7 +1129,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         M = m->M; A = m->A; B = m->B;
         mx = (t == 3) ? M : umax(A, B);
         nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
-        qv = w + m->qv_off[t]; qv_n = m->qv_n[t];
+        qv_n = m->qv_n[t];
         hw = w + m->hw_off[t]; hw_n = m->hw_n[t];
         s_top = lvl_s(h->lvl[mx + 1]);
         nd_leaf = lvl_nd(h->lvl[mx]);
