@@ -224,27 +224,130 @@ def fri_paths(proof: bytes, n_queries: int, max_log: int, n_trees: int, inputs=S
 
 
 def proof_layout(proof: bytes):
-    """Word offsets of the variable part of a proof: FRI layer commitments etc."""
+    """Word offsets of the variable part of a proof: FRI layer commitments and the position of
+    every u64 length prefix (`prefixes`: (word offset, count, what))."""
     w = np.frombuffer(proof, dtype=np.uint32)
-    pos = 895 + 2
-    for _ in range(4):
-        nh = int(w[pos]); pos += 2 + 8 * nh + 2
-    pos += 2
-    for _ in range(4):
-        nv = int(w[pos]); pos += 2 + nv
+    prefixes = []
+    pos = 895
+    prefixes.append((pos, int(w[pos]), "decommitments")); pos += 2
+    for t in range(4):
+        nh = int(w[pos]); prefixes.append((pos, nh, f"hash_witness[{t}]")); pos += 2 + 8 * nh
+        prefixes.append((pos, int(w[pos]), f"column_witness[{t}]")); pos += 2
+    prefixes.append((pos, int(w[pos]), "queried_values")); pos += 2
+    for t in range(4):
+        nv = int(w[pos]); prefixes.append((pos, nv, f"queried_values[{t}]")); pos += 2 + nv
     pos += 2  # proof-of-work nonce
     layers = []
 
-    def layer(pos):
-        nw = int(w[pos]); pos += 2 + 4 * nw
-        nh = int(w[pos]); pos += 2 + 8 * nh + 2
+    def layer(pos, name):
+        nw = int(w[pos]); prefixes.append((pos, nw, name + ".fri_witness")); pos += 2 + 4 * nw
+        nh = int(w[pos]); prefixes.append((pos, nh, name + ".hash_witness")); pos += 2 + 8 * nh
+        prefixes.append((pos, int(w[pos]), name + ".column_witness")); pos += 2
         return pos + 8, w[pos:pos + 8].copy()
 
-    pos, c0 = layer(pos)
+    pos, c0 = layer(pos, "first")
     layers.append(c0)
+    n_inner = int(w[pos]); prefixes.append((pos, n_inner, "inner_layers")); pos += 2
+    for i in range(n_inner):
+        pos, ci = layer(pos, f"inner[{i}]")
+        layers.append(ci)
+    prefixes.append((pos, int(w[pos]), "last_layer_poly"))
+    return {"lp": int(w[0]), "lq": int(w[1]), "blowup": int(w[11]), "log_last": int(w[12]), "nq": int(w[13]),
+            "fri_commitments": layers, "n_inner": n_inner, "prefixes": prefixes}
+
+
+def split_variable_part(proof: bytes):
+    """Parse the variable part of a proof (from word 895) into Python lists of uint32 arrays so that a
+    test can re-serialize a structurally valid but inconsistent proof (see join_variable_part)."""
+    w = np.frombuffer(proof, dtype=np.uint32)
+    pos = 895 + 2
+    d = {"head": w[:895].copy(), "hash_witness": [], "queried_values": [], "layers": []}
+    for _ in range(4):
+        nh = int(w[pos]); pos += 2
+        d["hash_witness"].append([w[pos + 8 * k:pos + 8 * k + 8].copy() for k in range(nh)]); pos += 8 * nh + 2
+    pos += 2
+    for _ in range(4):
+        nv = int(w[pos]); pos += 2
+        d["queried_values"].append(list(w[pos:pos + nv])); pos += nv
+    d["nonce"] = w[pos:pos + 2].copy(); pos += 2
+
+    def layer(pos):
+        nw = int(w[pos]); pos += 2
+        wit = [w[pos + 4 * k:pos + 4 * k + 4].copy() for k in range(nw)]; pos += 4 * nw
+        nh = int(w[pos]); pos += 2
+        hw = [w[pos + 8 * k:pos + 8 * k + 8].copy() for k in range(nh)]; pos += 8 * nh + 2
+        return pos + 8, {"fri_witness": wit, "hash_witness": hw, "commitment": w[pos:pos + 8].copy()}
+
+    pos, first = layer(pos)
+    d["layers"].append(first)
     n_inner = int(w[pos]); pos += 2
     for _ in range(n_inner):
-        pos, ci = layer(pos)
-        layers.append(ci)
-    return {"lp": int(w[0]), "lq": int(w[1]), "blowup": int(w[11]), "log_last": int(w[12]), "nq": int(w[13]),
-            "fri_commitments": layers, "n_inner": n_inner}
+        pos, l = layer(pos)
+        d["layers"].append(l)
+    nl = int(w[pos]); pos += 2
+    d["last"] = [w[pos + 4 * k:pos + 4 * k + 4].copy() for k in range(nl)]; pos += 4 * nl
+    d["tail"] = w[pos:].copy()
+    return d
+
+
+def join_variable_part(d) -> bytes:
+    def u64(n):
+        return np.array([n & 0xFFFFFFFF, n >> 32], dtype=np.uint32)
+
+    def cat(items, width):
+        return np.concatenate([np.asarray(x, dtype=np.uint32).reshape(width) for x in items]) if items else np.zeros(0, np.uint32)
+
+    out = [d["head"], u64(4)]
+    for t in range(4):
+        out += [u64(len(d["hash_witness"][t])), cat(d["hash_witness"][t], 8), u64(0)]
+    out.append(u64(4))
+    for t in range(4):
+        out += [u64(len(d["queried_values"][t])), np.asarray(d["queried_values"][t], dtype=np.uint32)]
+    out.append(d["nonce"])
+    for i, l in enumerate(d["layers"]):
+        if i == 1:
+            out.append(u64(len(d["layers"]) - 1))
+        out += [u64(len(l["fri_witness"])), cat(l["fri_witness"], 4), u64(len(l["hash_witness"])), cat(l["hash_witness"], 8),
+                u64(0), l["commitment"]]
+    if len(d["layers"]) == 1:
+        out.append(u64(0))
+    out += [u64(len(d["last"])), cat(d["last"], 4), d["tail"]]
+    return np.concatenate([np.asarray(x, dtype=np.uint32) for x in out]).tobytes()
+
+
+def structural_mutants(proof: bytes):
+    """Structurally valid re-serializations with one list one element too short / too long, or with elements moved:
+    they parse, and must fail in the stage that consumes the list.  Returns [(tag, bytes)]."""
+    import copy
+    base = split_variable_part(proof)
+    out = []
+
+    def emit(tag, d):
+        out.append((tag, join_variable_part(d)))
+
+    zero8, zero4 = np.zeros(8, np.uint32), np.zeros(4, np.uint32)
+    for t in range(4):
+        d = copy.deepcopy(base); d["hash_witness"][t].pop(); emit(f"hw[{t}]-1", d)
+        d = copy.deepcopy(base); d["hash_witness"][t].append(zero8); emit(f"hw[{t}]+1", d)
+        d = copy.deepcopy(base); d["hash_witness"][t].insert(0, d["hash_witness"][t].pop()); emit(f"hw[{t}] rotated", d)
+        d = copy.deepcopy(base); d["queried_values"][t].pop(); emit(f"qv[{t}]-1", d)
+        d = copy.deepcopy(base); d["queried_values"][t].append(np.uint32(7)); emit(f"qv[{t}]+1", d)
+        d = copy.deepcopy(base); d["queried_values"][t] = d["queried_values"][t][: len(d["queried_values"][t]) // 2]; emit(f"qv[{t}] halved", d)
+        d = copy.deepcopy(base); d["hash_witness"][t] = []; emit(f"hw[{t}] empty", d)
+    d = copy.deepcopy(base); d["hash_witness"][1].append(d["hash_witness"][0].pop()); emit("hw[0]->hw[1]", d)
+    d = copy.deepcopy(base); d["queried_values"][1].append(d["queried_values"][0].pop()); emit("qv[0]->qv[1]", d)
+    for i in range(len(base["layers"])):
+        for key, z in (("fri_witness", zero4), ("hash_witness", zero8)):
+            if base["layers"][i][key]:
+                d = copy.deepcopy(base); d["layers"][i][key].pop(); emit(f"layer[{i}].{key}-1", d)
+                d = copy.deepcopy(base); d["layers"][i][key] = []; emit(f"layer[{i}].{key} empty", d)
+            d = copy.deepcopy(base); d["layers"][i][key].append(z); emit(f"layer[{i}].{key}+1", d)
+    if len(base["layers"]) > 2:
+        d = copy.deepcopy(base); d["layers"].pop(); emit("inner layers -1", d)
+        d = copy.deepcopy(base); d["layers"].append(copy.deepcopy(d["layers"][-1])); emit("inner layers +1", d)
+        d = copy.deepcopy(base); d["layers"][1], d["layers"][2] = d["layers"][2], d["layers"][1]; emit("inner layers swapped", d)
+    d = copy.deepcopy(base); d["last"].pop(); emit("last-1", d)
+    d = copy.deepcopy(base); d["last"].append(zero4); emit("last+1", d)
+    d = copy.deepcopy(base); d["last"] = d["last"] + d["last"]; emit("last doubled", d)
+    d = copy.deepcopy(base); d["last"] = []; emit("last empty", d)
+    return out

@@ -335,3 +335,46 @@ def test_fri_paths_match_oracle(rsv, manifest, name):
         for s2 in range(1 + n_inner):
             d = M if s2 == 0 else M - s2
             assert np.array_equal(sib[k, s2, :, :d - 1, :], osib[s2, :, :d - 1, :]), (k, s2)
+
+
+def _prefix_mutants(proof):
+    out = []
+    for pos, n, _ in ob.proof_layout(proof)["prefixes"]:
+        for val in {max(n - 1, 0), n + 1, 0, 0xFFFFFFFF, (1 << 32) + n, 8 * n + 3} - {n}:
+            b = bytearray(proof)
+            b[4 * pos:4 * pos + 8] = int(val).to_bytes(8, "little")
+            out.append(bytes(b))
+    return out
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "level12-1.bin", "level2-1.bin"])
+def test_every_length_prefix_mutated_matches_oracle(rsv, manifest, name):
+    """Robustness: every u64 length prefix of the variable part (decommitments, queried values, FRI layers, last
+    layer) set to n-1, n+1, 0, 2^32-1, 2^32+n and 8n+3.  No launch may fault; verdict and reason == oracle's."""
+    entry = next(e for e in manifest if e["file"] == name)
+    inputs = entry_inputs(entry)
+    proof = read_proof(name)
+    batch = _prefix_mutants(proof) + [proof]
+    acc, reason = rsv.verify_batch(batch, inputs)
+    oacc, oreason = ob.verify_batch(batch, inputs)
+    assert acc.tolist() == oacc.tolist()
+    assert reason.tolist() == oreason.tolist()
+    assert acc[-1] == 1 and int(acc[:-1].sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "level12-1.bin", "level2-1.bin", "level1-5.bin"])
+def test_structural_mutants_match_oracle(rsv, manifest, name):
+    """Well-formed proofs whose witness lists are one element short / long, emptied, rotated or moved between trees
+    and layers (tests/oracle_binding.py::structural_mutants): they pass the parser and must fail in the stage that
+    consumes the list, with the oracle's reason, and without any out-of-range access."""
+    entry = next(e for e in manifest if e["file"] == name)
+    inputs = entry_inputs(entry)
+    proof = read_proof(name)
+    mut = ob.structural_mutants(proof)
+    batch = [b for _, b in mut] + [proof]
+    acc, reason = rsv.verify_batch(batch, inputs)
+    oacc, oreason = ob.verify_batch(batch, inputs)
+    bad = [(mut[i][0], int(reason[i]), int(oreason[i])) for i in range(len(mut)) if reason[i] != oreason[i]]
+    assert not bad, bad
+    assert acc.tolist() == oacc.tolist()
+    assert acc[-1] == 1 and int(acc[:-1].sum()) == 0

@@ -239,3 +239,35 @@ def test_fri_paths_verify_against_commitments():
                 query = int(raw[q]) >> (M - depth)
                 root = _pair_path_root(query, depth, data_levels, sib[s2, q], cols[s2, q])
                 assert root.tolist() == lay["fri_commitments"][s2].tolist(), (name, s2, q)
+
+
+def test_every_length_prefix_mutated_is_rejected():
+    """Every u64 length prefix of the variable part perturbed: the oracle must reject (and not crash)."""
+    proof = read_proof("small_proof.bin")
+    batch = []
+    for pos, n, _ in ob.proof_layout(proof)["prefixes"]:
+        for val in {max(n - 1, 0), n + 1, 0, 0xFFFFFFFF, (1 << 32) + n, 8 * n + 3} - {n}:
+            b = bytearray(proof)
+            b[4 * pos:4 * pos + 8] = int(val).to_bytes(8, "little")
+            batch.append(bytes(b))
+    acc, reason = ob.verify_batch(batch + [proof], [(1, (1, 0, 0, 0))])
+    assert acc[-1] == 1 and int(acc[:-1].sum()) == 0
+    assert set(reason[:-1].tolist()) <= set(range(1, 13))
+
+
+def test_structural_mutants_fail_in_the_consuming_stage():
+    """Re-serialized proofs with one witness list perturbed parse fine and fail where the list is consumed
+    (reasons: 6..9 = trace tree t, 10 = FRI first layer, 11 = FRI inner layers, 1 = parser's shape rules)."""
+    proof = read_proof("small_proof.bin")
+    mut = ob.structural_mutants(proof)
+    acc, reason = ob.verify_batch([b for _, b in mut], [(1, (1, 0, 0, 0))])
+    assert int(acc.sum()) == 0
+    for (tag, _), r in zip(mut, reason.tolist()):
+        if tag.startswith(("hw[", "qv[")):
+            assert r == 6 + int(tag[3]), (tag, r)
+        elif tag.startswith("layer[0]"):
+            assert r == 10, (tag, r)
+        elif tag.startswith("layer["):
+            assert r == 11, (tag, r)
+        elif tag.startswith("last") or tag in ("inner layers -1", "inner layers +1"):
+            assert r == 1, (tag, r)
