@@ -114,7 +114,8 @@ def main():
     ap.add_argument("--perm-log2", type=int, default=24, help="Poseidon2 microbench size (log2 states, 0 = skip)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="standard")
     ap.add_argument("--emit-paths", action="store_true",
-                    help="also emit the per-query trace-tree paths (SURVEY 8f.1); needs a uniform-shape workload")
+                    help="also emit every hint output (transcript rows, trace-tree and FRI per-query paths; SURVEY 8f.1) from the "
+                         "verifying pass; needs a uniform-shape workload")
     args = ap.parse_args()
 
     import torch
@@ -155,16 +156,21 @@ def main():
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
     d_all = torch.zeros(world * n_words, dtype=torch.int32, device=dev) if world > 1 else None
     ctx = rsv.Context(dev_index)
-    d_sib = d_pos = None
+    hints = None
     if args.emit_paths:
         hdr = np.frombuffer(read_fixture(fixtures[0])[:64], dtype=np.uint32)
         p_nq, p_M = int(hdr[13]), max(int(hdr[0]) + 1, int(hdr[1]) + 2) + int(hdr[11])
-        d_sib = torch.zeros((n, 4, p_nq, p_M, 8), dtype=torch.int32, device=dev)
-        d_pos = torch.zeros((n, 4, p_nq), dtype=torch.int32, device=dev)
+        p_inner = p_M - int(hdr[11]) - int(hdr[12]) - 1  # FRI inner layers: folds from log M-blowup down to log_last
+        hints = dict(shape=(p_nq, p_M, p_inner),
+                     d_transcript=torch.zeros((n, rsv.TRANSCRIPT_WORDS), dtype=torch.int32, device=dev),
+                     d_trace_sib=torch.zeros((n, 4, p_nq, p_M, 8), dtype=torch.int32, device=dev),
+                     d_trace_pos=torch.zeros((n, 4, p_nq), dtype=torch.int32, device=dev),
+                     d_fri_sib=torch.zeros((n, 1 + p_inner, p_nq, p_M, 8), dtype=torch.int32, device=dev),
+                     d_fri_cols=torch.zeros((n, 1 + p_inner, p_nq, 3, 8), dtype=torch.int32, device=dev))
 
     def step():
-        if args.emit_paths:
-            ctx.trace_paths(d_blob, d_offsets, n, p_nq, p_M, d_sib, d_pos, d_accept, d_reason)
+        if hints:
+            ctx.verify_hints(d_blob, d_offsets, n, d_accept, d_reason, **hints)
         else:
             ctx.verify_batch(d_blob, d_offsets, n, d_accept, d_reason)
         ctx.accept_bitmap(d_accept, n, d_bitmap, d_count)

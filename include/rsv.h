@@ -204,6 +204,30 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
                   uint32_t n_queries, uint32_t max_log, uint32_t n_inner, uint32_t* sib, uint32_t* cols, uint8_t* accept,
                   uint8_t* reason, int device);
 
+/* ---- everything the reference's hint structs need, from ONE verifying pass ------------------------
+ * rsv_verify_hints_dev = rsv_verify_batch_dev that also writes whichever of these outputs are non-NULL:
+ *   d_transcript [n][RSV_TRANSCRIPT_WORDS]  per proof, what FiatShamirHints (components/hints/src/fiat_shamir.rs:69-256)
+ *                                           carries: words [0..40) as rsv_transcript's; [40..40+4*29) the FRI alphas
+ *                                           (first layer, then inner layers; zero padded); [156..284) the raw query
+ *                                           words in transcript order (zero padded).  Mixed shapes allowed.
+ *   d_trace_sib / d_trace_pos               as rsv_trace_paths_dev   (both or neither)
+ *   d_fri_sib / d_fri_cols                  as rsv_fri_paths_dev     (both or neither)
+ * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE. */
+#define RSV_TRANSCRIPT_WORDS 284
+typedef struct {
+    uint32_t n_queries, max_log, n_inner; /* declared common shape; ignored when no path output is requested */
+    uint32_t* d_transcript;
+    uint32_t* d_trace_sib;
+    uint32_t* d_trace_pos;
+    uint32_t* d_fri_sib;
+    uint32_t* d_fri_cols;
+} rsv_hints_out;
+int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
+                         const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,
+                         uint8_t* d_reason);
+/* Host-buffer convenience for the transcript rows only (any mix of shapes): out is [n][RSV_TRANSCRIPT_WORDS]. */
+int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, uint32_t* out, int device);
+
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).
  * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */

@@ -52,6 +52,15 @@ class PublicInput(ctypes.Structure):
     _fields_ = [("idx", ctypes.c_uint32), ("value", ctypes.c_uint32 * 4)]
 
 
+class HintsOut(ctypes.Structure):  # rsv_hints_out
+    _fields_ = [("n_queries", ctypes.c_uint32), ("max_log", ctypes.c_uint32), ("n_inner", ctypes.c_uint32),
+                ("d_transcript", ctypes.c_void_p), ("d_trace_sib", ctypes.c_void_p), ("d_trace_pos", ctypes.c_void_p),
+                ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p)]
+
+
+TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
+
+
 def _load() -> ctypes.CDLL:
     # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  Import torch first so that
     # the process holds ONE runtime and the tensors torch allocates are visible to this library's stream.
@@ -86,6 +95,8 @@ def _load() -> ctypes.CDLL:
         "rsv_accept_bitmap_dev": (ctypes.c_int, [vp, vp, sz, vp, vp]),
         "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
+        "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
+        "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, _u32p, ctypes.c_int]),
         "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                              ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp]),
         "rsv_fri_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32, ctypes.c_uint32,
@@ -107,7 +118,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
-           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths"]
+           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_transcript_batch"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -257,6 +268,16 @@ def trace_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, inputs=ST
     return sib, pos, accept, reason
 
 
+def transcript_batch(proofs: Sequence[bytes], device: int = 0) -> np.ndarray:
+    """FiatShamirHints of every proof of a batch (any mix of shapes): uint32[n, TRANSCRIPT_WORDS], layout in rsv.h."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    out = np.zeros((n, TRANSCRIPT_WORDS), np.uint32)
+    _check(lib.rsv_transcript_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u32p),
+                                    device), "rsv_transcript_batch")
+    return out
+
+
 def fri_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
     """per-query pair paths of the FRI trees.  Returns (sib uint32[n,1+n_inner,nq,max_log,8],
     cols uint32[n,1+n_inner,nq,3,8], accept, reason)."""
@@ -319,6 +340,17 @@ class Context:
         _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
                                        n_queries, max_log, d_sib.data_ptr(), d_pos.data_ptr(), d_accept.data_ptr(),
                                        d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
+
+    def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
+                     d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_fri_sib=None, d_fri_cols=None):
+        """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
+        shape = (n_queries, max_log, n_inner), needed for the path outputs."""
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
+                      ptr(d_fri_sib), ptr(d_fri_cols))
+        pi = make_inputs(inputs)
+        _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
+                                        ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")
 
     def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):
         _check(lib.rsv_accept_bitmap_dev(self._h, d_accept.data_ptr(), n, d_bitmap.data_ptr(),

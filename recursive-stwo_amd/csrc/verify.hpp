@@ -682,6 +682,35 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
 #undef SQ
 }
 
+// ------------------------------------------------------------------ k_export_transcript
+// One lane per output word: ProofCtx -> the flat row layout of include/rsv.h (RSV_TRANSCRIPT_WORDS).
+constexpr uint32_t TR_WORDS = 40 + 4 * (MAX_INNER + 1) + MAXQ;
+__global__ __launch_bounds__(256) void k_export_transcript(uint32_t n, const ProofMeta* __restrict__ metas,
+                                                            const ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * TR_WORDS) return;
+    const uint32_t p = (uint32_t)(gid / TR_WORDS), k = (uint32_t)(gid % TR_WORDS);
+    const ProofMeta& m = metas[p];
+    const ProofCtx& c = ctxs[p];
+    uint32_t v = 0;
+    if (m.reason != R_OK) v = k == 0 ? (uint32_t)R_PARSE : 0u;
+    else if (k == 0) v = (c.flags & (1u << R_POW)) ? (uint32_t)R_POW : (uint32_t)R_OK;
+    else if (k == 1) v = m.n_inner + 1;
+    else if (k == 2) v = m.nq;
+    else if (k == 3) v = m.M;
+    else if (k < 8) v = c.z[k - 4];
+    else if (k < 12) v = c.alpha[k - 8];
+    else if (k < 16) v = c.rc[k - 12];
+    else if (k < 20) v = c.oods_t[k - 16];
+    else if (k < 24) v = c.oods_x[k - 20];
+    else if (k < 28) v = c.oods_y[k - 24];
+    else if (k < 32) v = c.after[k - 28];
+    else if (k < 40) v = c.pow_digest[k - 32];
+    else if (k < 40 + 4 * (MAX_INNER + 1)) { uint32_t a = (k - 40) >> 2; v = a <= m.n_inner ? c.fri_alpha[a][(k - 40) & 3] : 0u; }
+    else { uint32_t q = k - (40 + 4 * (MAX_INNER + 1)); v = q < m.nq ? c.raw_q[q] : 0u; }
+    out[gid] = v;
+}
+
 // ------------------------------------------------------------------ k_qconst
 // One lane per proof: the query-independent constants of the DEEP quotients — alpha powers and, per column
 // log size and sample point, the summed line coefficients.  Needs only the transcript, so it runs on the side

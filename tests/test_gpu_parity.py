@@ -378,3 +378,70 @@ def test_structural_mutants_match_oracle(rsv, manifest, name):
     assert not bad, bad
     assert acc.tolist() == oacc.tolist()
     assert acc[-1] == 1 and int(acc[:-1].sum()) == 0
+
+
+def _row_from_raw(raw):
+    """rsv_transcript's packed layout (oracle: rsvo_transcript) -> the fixed-stride row of rsv_transcript_batch."""
+    row = np.zeros(284, np.uint32)
+    if raw[0] == 1:  # RSV_R_PARSE
+        row[0] = 1
+        return row
+    na, nq = int(raw[1]), int(raw[2])
+    row[:40] = raw[:40]
+    row[40:40 + 4 * na] = raw[40:40 + 4 * na]
+    row[156:156 + nq] = raw[40 + 4 * na:40 + 4 * na + nq]
+    return row
+
+
+def test_transcript_batch_matches_oracle(rsv, manifest):
+    """FiatShamirHints rows for a mixed-shape batch: all fixtures, the SHA-256-channel fixture (parse reject), a
+    proof with a flipped commitment byte (PoW reject) and garbage."""
+    proofs = [read_proof(e["file"]) for e in manifest]
+    bad = bytearray(proofs[0]); bad[70] ^= 1
+    proofs += [read_proof("hybrid_hash.bin"), bytes(bad), b"\x00" * 64]
+    rows = rsv.transcript_batch(proofs)
+    for i, pr in enumerate(proofs):
+        want = _row_from_raw(ob.transcript_raw(pr)) if len(pr) >= 4096 else _row_from_raw(np.array([1], np.uint32))
+        assert np.array_equal(rows[i], want), i
+    assert rsv.transcript_batch([b"\x00" * 64, b"\x01" * 8])[:, 0].tolist() == [1, 1]  # nothing parses
+
+
+def test_verify_hints_one_pass(rsv, manifest):
+    """rsv_verify_hints_dev: verdicts + transcript rows + trace paths + FRI paths from ONE pass == the three
+    single-purpose entry points."""
+    import torch
+    entry = next(e for e in manifest if e["file"] == "recursive_proof_16_15.bin")
+    proof = read_proof(entry["file"])
+    lay = ob.proof_layout(proof)
+    nq, n_inner = entry["n_queries"], lay["n_inner"]
+    M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
+    n = 40
+    batch = [ob.tamper(proof, i) if i % 9 == 4 else proof for i in range(n)]
+    blob, offsets = rsv.pack(batch)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_tr = torch.zeros((n, rsv.TRANSCRIPT_WORDS), dtype=torch.int32, device=dev)
+    d_ts = torch.zeros((n, 4, nq, M, 8), dtype=torch.int32, device=dev)
+    d_tp = torch.zeros((n, 4, nq), dtype=torch.int32, device=dev)
+    d_fs = torch.zeros((n, 1 + n_inner, nq, M, 8), dtype=torch.int32, device=dev)
+    d_fc = torch.zeros((n, 1 + n_inner, nq, 3, 8), dtype=torch.int32, device=dev)
+    ctx = rsv.Context(0)
+    ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq, M, n_inner), d_transcript=d_tr, d_trace_sib=d_ts,
+                     d_trace_pos=d_tp, d_fri_sib=d_fs, d_fri_cols=d_fc)
+    ctx.synchronize()
+    oacc, oreason = ob.verify_batch(batch)
+    assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
+    tr = d_tr.cpu().numpy().view(np.uint32)
+    assert np.array_equal(tr, rsv.transcript_batch(batch))
+    tsib, tpos, _, _ = rsv.trace_paths(batch, nq, M)
+    fsib, fcols, _, _ = rsv.fri_paths(batch, nq, M, n_inner)
+    ok = np.nonzero(oacc)[0]
+    assert np.array_equal(d_ts.cpu().numpy().view(np.uint32)[ok], tsib[ok]) and np.array_equal(d_tp.cpu().numpy().view(np.uint32)[ok], tpos[ok])
+    assert np.array_equal(d_fs.cpu().numpy().view(np.uint32)[ok], fsib[ok]) and np.array_equal(d_fc.cpu().numpy().view(np.uint32)[ok], fcols[ok])
+    # a shape that does not match the batch is an API error, not a verdict
+    with pytest.raises(rsv.RsvError):
+        ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq + 1, M, n_inner), d_trace_sib=d_ts, d_trace_pos=d_tp)
+    ctx.close()
