@@ -165,6 +165,7 @@ def main():
                      d_transcript=torch.zeros((n, rsv.TRANSCRIPT_WORDS), dtype=torch.int32, device=dev),
                      d_trace_sib=torch.zeros((n, 4, p_nq, p_M, 8), dtype=torch.int32, device=dev),
                      d_trace_pos=torch.zeros((n, 4, p_nq), dtype=torch.int32, device=dev),
+                     d_trace_cols=torch.zeros((n, 4, p_nq, 64), dtype=torch.int32, device=dev),
                      d_fri_sib=torch.zeros((n, 1 + p_inner, p_nq, p_M, 8), dtype=torch.int32, device=dev),
                      d_fri_cols=torch.zeros((n, 1 + p_inner, p_nq, 3, 8), dtype=torch.int32, device=dev))
 

@@ -211,6 +211,9 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  *                                           (first layer, then inner layers; zero padded); [156..284) the raw query
  *                                           words in transcript order (zero padded).  Mixed shapes allowed.
  *   d_trace_sib / d_trace_pos               as rsv_trace_paths_dev   (both or neither)
+ *   d_trace_cols [n][4][n_queries][64]      optional, with d_trace_sib: SinglePathMerkleProof::columns — the query's
+ *                                           column values at the leaf level, then those at the lower column log size
+ *                                           (the packing rsv_merkle_path_root takes)
  *   d_fri_sib / d_fri_cols                  as rsv_fri_paths_dev     (both or neither)
  * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE. */
 #define RSV_TRANSCRIPT_WORDS 284
@@ -219,6 +222,7 @@ typedef struct {
     uint32_t* d_transcript;
     uint32_t* d_trace_sib;
     uint32_t* d_trace_pos;
+    uint32_t* d_trace_cols;
     uint32_t* d_fri_sib;
     uint32_t* d_fri_cols;
 } rsv_hints_out;

@@ -987,6 +987,7 @@ typedef struct {
     uint32_t qM[MAX_QUERIES], M, maxlog[4], nq;
     pair_record* pair_records; /* [1 + n_inner] or NULL */
     uint32_t n_inner;
+    uint32_t* trace_cols; /* [4][nq][64] or NULL: per query, the leaf-level columns then the lower-level columns */
 } query_probe;
 
 static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config* cfg,
@@ -1030,6 +1031,17 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
                                         v->commitments[tr], cols[tr]);
         g_record = NULL;
         if (!tree_ok) FAIL(RSV_R_MERKLE_T0 + tr);
+        if (probe->trace_cols) { /* SinglePathMerkleProof::columns (components/hints/src/decommit.rs:158-170) */
+            probe->M = M; probe->nq = nq;
+            for (uint32_t j = 0; j < nq; j++) {
+                uint32_t* dst = probe->trace_cols + ((size_t)tr * nq + j) * 64, k = 0;
+                for (uint32_t l = maxlog + 1; l-- > 0;) {
+                    if (!ncols_at[l]) continue;
+                    const uint32_t* src = find_cols(&cols[tr][l], q[j] >> (maxlog - l));
+                    for (uint32_t e = 0; e < ncols_at[l]; e++) dst[k++] = src ? src[e] : 0xFFFFFFFFu;
+                }
+            }
+        }
     }
     /* quotient groups by descending column log size: answer/src/lib.rs:294-315 */
     uint32_t sizes[3]; uint32_t n_sizes = 0;
@@ -1251,6 +1263,20 @@ int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* p
 done:
     free(pr->records); free(pr);
     return rc;
+}
+
+/* SinglePathMerkleProof::columns for the same paths: cols [4][nq][64], per query the columns at the leaf level
+ * followed by the columns at the lower column log size (trees 0..2 when lp + 1 != lq + 2... i.e. A != B). */
+int rsvo_trace_cols(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* cols, size_t cap,
+                    uint32_t* n_queries) {
+    if (!proof || !cols || !n_queries) return RSV_E_NULL;
+    if (cap < (size_t)4 * MAX_QUERIES * 64) return RSV_E_CAP;
+    query_probe* pr = calloc(1, sizeof *pr);
+    pr->trace_cols = cols;
+    uint8_t r = verify_one(proof, len, NULL, pi, n_pi, pr);
+    *n_queries = pr->nq;
+    free(pr);
+    return r == RSV_R_OK ? RSV_OK : RSV_E_SIZE;
 }
 
 /* SURVEY 8f.1, pair trees: what SinglePairMerkleProof::from_stwo_proof (components/hints/src/folding.rs:214-287)

@@ -58,6 +58,8 @@ int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* 
  * sib [4][n_queries][M][8] (k-th level above the leaf at index k), pos [4][n_queries], depth4 [4]. */
 int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
                      size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries);
+int rsvo_trace_cols(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* cols, size_t cap,
+                    uint32_t* n_queries);
 
 /* SURVEY 8f.1, pair trees (layout: see rsv_oracle.c). */
 int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,

@@ -1054,6 +1054,9 @@ struct MerkleArgs {
     //   path_pos[(slot*4 + t)*G + i]              = position of query i at the tree's leaf level
     uint32_t* path_sib;
     uint32_t* path_pos;
+    //   path_cols[((slot*4 + t)*G + i)*64 + k]    = SinglePathMerkleProof::columns: the leaf-level column values of
+    //                                               query i, then those at the lower column log size (may be null)
+    uint32_t* path_cols;
     // optional per-query pair paths of the FRI trees (SinglePairMerkleProof, components/hints/src/folding.rs:214-287):
     //   pair_sib [(((slot*(1+maxInner) + s)*G + i)*maxM + k]  sibling_hashes[k] of tree s (0 = first layer), 8 words
     //   pair_cols[(((slot*(1+maxInner) + s)*G + i)*3 + c]     c-th data level from the top: self | sibling value, 8 words
@@ -1166,7 +1169,14 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         rows = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
         const uint32_t row = ent_rb(ent[mx * G + j]);
         if ((row + 1) * nc_leaf > qv_n) bad = true;
-        else cur = load_hash(rows + (size_t)row * 8);
+        else {
+            cur = load_hash(rows + (size_t)row * 8);
+            if (a.path_cols) {
+                uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64;
+                const uint32_t* src = w + m->qv_off[t] + row * nc_leaf;
+                for (uint32_t k = 0; k < nc_leaf; k++) pc[k] = src[k];
+            }
+        }
     }
     if (Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
@@ -1204,7 +1214,14 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
                 const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
                 const uint32_t off = nd_leaf * nc_leaf + row * nc;
                 if (off + nc > qv_n || nd_lower - 1 - row >= a.Grow) bad = true;
-                else cur = combine_with_column(cur, load_hash(rows + ((size_t)a.Grow + (nd_lower - 1 - row)) * 8));
+                else {
+                    cur = combine_with_column(cur, load_hash(rows + ((size_t)a.Grow + (nd_lower - 1 - row)) * 8));
+                    if (a.path_cols) {
+                        uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64 + nc_leaf;
+                        const uint32_t* src = w + m->qv_off[t] + off;
+                        for (uint32_t k = 0; k < nc; k++) pc[k] = src[k];
+                    }
+                }
             }
         }
     }

@@ -207,6 +207,22 @@ def trace_paths(proof: bytes, n_queries: int, max_log: int, inputs=STANDARD_INPU
     return sib, pos, depth
 
 
+def trace_cols(proof: bytes, inputs=STANDARD_INPUTS):
+    """-> uint32[4, nq, 64]: SinglePathMerkleProof::columns per query, leaf-level columns then lower-level ones."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    cols = np.zeros(4 * 128 * 64, np.uint32)
+    nq = np.zeros(1, np.uint32)
+    pi = make_inputs(inputs)
+    lib.rsvo_trace_cols.restype = ctypes.c_int
+    lib.rsvo_trace_cols.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p]
+    rc = lib.rsvo_trace_cols(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), cols.ctypes.data_as(_u32p), cols.size,
+                             nq.ctypes.data_as(_u32p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_trace_cols -> {rc}")
+    n = int(nq[0])
+    return cols[:4 * n * 64].reshape(4, n, 64).copy()
+
+
 def fri_paths(proof: bytes, n_queries: int, max_log: int, n_trees: int, inputs=STANDARD_INPUTS):
     """-> (sib uint32[n_trees, nq, M, 8], cols uint32[n_trees, nq, 3, 8])."""
     b = np.frombuffer(proof, dtype=np.uint8)

@@ -426,11 +426,12 @@ def test_verify_hints_one_pass(rsv, manifest):
     d_tr = torch.zeros((n, rsv.TRANSCRIPT_WORDS), dtype=torch.int32, device=dev)
     d_ts = torch.zeros((n, 4, nq, M, 8), dtype=torch.int32, device=dev)
     d_tp = torch.zeros((n, 4, nq), dtype=torch.int32, device=dev)
+    d_tc = torch.zeros((n, 4, nq, 64), dtype=torch.int32, device=dev)
     d_fs = torch.zeros((n, 1 + n_inner, nq, M, 8), dtype=torch.int32, device=dev)
     d_fc = torch.zeros((n, 1 + n_inner, nq, 3, 8), dtype=torch.int32, device=dev)
     ctx = rsv.Context(0)
     ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq, M, n_inner), d_transcript=d_tr, d_trace_sib=d_ts,
-                     d_trace_pos=d_tp, d_fri_sib=d_fs, d_fri_cols=d_fc)
+                     d_trace_pos=d_tp, d_trace_cols=d_tc, d_fri_sib=d_fs, d_fri_cols=d_fc)
     ctx.synchronize()
     oacc, oreason = ob.verify_batch(batch)
     assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
@@ -441,6 +442,21 @@ def test_verify_hints_one_pass(rsv, manifest):
     ok = np.nonzero(oacc)[0]
     assert np.array_equal(d_ts.cpu().numpy().view(np.uint32)[ok], tsib[ok]) and np.array_equal(d_tp.cpu().numpy().view(np.uint32)[ok], tpos[ok])
     assert np.array_equal(d_fs.cpu().numpy().view(np.uint32)[ok], fsib[ok]) and np.array_equal(d_fc.cpu().numpy().view(np.uint32)[ok], fcols[ok])
+    # SinglePathMerkleProof::columns, and the whole struct through the path verifier: every path -> its commitment
+    tcols = d_tc.cpu().numpy().view(np.uint32)
+    assert np.array_equal(tcols[ok[0]], ob.trace_cols(proof))
+    words = np.frombuffer(proof, dtype=np.uint32)
+    A, B = entry["log_size_plonk"] + entry["log_blowup_factor"], entry["log_size_poseidon"] + entry["log_blowup_factor"]
+    for t in range(4):
+        d = M if t == 3 else max(A, B)
+        n_cols_at = [0] * (d + 1)
+        if t == 3:
+            n_cols_at[M] = 8
+        else:
+            n_cols_at[A] += [10, 12, 8][t]
+            n_cols_at[B] += [40, 48, 8][t]
+        roots = rsv.merkle_path_root(tpos[ok[1], t], tsib[ok[1], t][:, :d, :], tcols[ok[1], t][:, :sum(n_cols_at)], n_cols_at)
+        assert all(r.tolist() == words[17 + 8 * t:25 + 8 * t].tolist() for r in roots), t
     # a shape that does not match the batch is an API error, not a verdict
     with pytest.raises(rsv.RsvError):
         ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq + 1, M, n_inner), d_trace_sib=d_ts, d_trace_pos=d_tp)

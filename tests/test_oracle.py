@@ -271,3 +271,31 @@ def test_structural_mutants_fail_in_the_consuming_stage():
             assert r == 11, (tag, r)
         elif tag.startswith("last") or tag in ("inner layers -1", "inner layers +1"):
             assert r == 1, (tag, r)
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level12-1.bin"])
+def test_trace_paths_with_columns_recompute_all_four_roots(name):
+    """SinglePathMerkleProof {query, sibling_hashes, columns} per query and tree -> verify() (decommit.rs:22-42):
+    every path of every tree recomputes the tree's commitment."""
+    entry = next(e for e in load_manifest() if e["file"] == name)
+    inputs = [(i, tuple(v)) for i, v in entry["inputs"]]
+    proof = read_proof(name)
+    words = np.frombuffer(proof, dtype=np.uint32)
+    lp, lq, blowup, nq = int(words[0]), int(words[1]), int(words[11]), int(words[13])
+    A, B = lp + blowup, lq + blowup
+    M = max(lp + 1, lq + 2) + blowup
+    sib, pos, depth = ob.trace_paths(proof, nq, M, inputs)
+    cols = ob.trace_cols(proof, inputs)
+    plonk, poseidon = [10, 12, 8], [40, 48, 8]
+    for t in range(4):
+        d = int(depth[t])
+        n_cols_at = [0] * (d + 1)
+        if t == 3:
+            n_cols_at[M] = 8
+        else:
+            n_cols_at[A] += plonk[t]
+            n_cols_at[B] += poseidon[t]
+        tot = sum(n_cols_at)
+        roots = ob.merkle_path_root(pos[t], sib[t][:, :d, :], cols[t][:, :tot], n_cols_at)
+        want = words[17 + 8 * t:25 + 8 * t]
+        assert all(r.tolist() == want.tolist() for r in roots), t
