@@ -167,7 +167,8 @@ def main():
                      d_trace_pos=torch.zeros((n, 4, p_nq), dtype=torch.int32, device=dev),
                      d_trace_cols=torch.zeros((n, 4, p_nq, 64), dtype=torch.int32, device=dev),
                      d_fri_sib=torch.zeros((n, 1 + p_inner, p_nq, p_M, 8), dtype=torch.int32, device=dev),
-                     d_fri_cols=torch.zeros((n, 1 + p_inner, p_nq, 3, 8), dtype=torch.int32, device=dev))
+                     d_fri_cols=torch.zeros((n, 1 + p_inner, p_nq, 3, 8), dtype=torch.int32, device=dev),
+                     d_fri_folded=torch.zeros((n, 3, p_nq, 4), dtype=torch.int32, device=dev))
 
     def step():
         if hints:

@@ -215,6 +215,9 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  *                                           column values at the leaf level, then those at the lower column log size
  *                                           (the packing rsv_merkle_path_root takes)
  *   d_fri_sib / d_fri_cols                  as rsv_fri_paths_dev     (both or neither)
+ *   d_fri_folded [n][3][n_queries][4]       optional, with d_fri_sib: FirstLayerHints::folded_evals_by_column
+ *                                           (components/hints/src/folding.rs:291-293) — the circle-to-line fold of
+ *                                           each query's first-layer pair at the c-th column log size (descending)
  * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE. */
 #define RSV_TRANSCRIPT_WORDS 284
 typedef struct {
@@ -225,6 +228,7 @@ typedef struct {
     uint32_t* d_trace_cols;
     uint32_t* d_fri_sib;
     uint32_t* d_fri_cols;
+    uint32_t* d_fri_folded;
 } rsv_hints_out;
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,

@@ -981,6 +981,7 @@ typedef struct {
     /* per query j (transcript order) */
     qm31 answers[3][MAX_QUERIES];
     qm31 last_value[MAX_QUERIES];
+    qm31 first_folded[3][MAX_QUERIES]; /* FirstLayerHints::folded_evals_by_column, per size group and query */
     uint32_t n_sizes;
     /* optional: per-path extraction of the trace trees (rsvo_trace_paths) */
     tree_record* records; /* [4] or NULL */
@@ -1122,6 +1123,7 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
                 first[gi][j] = f;
             }
         }
+        memcpy(probe->first_folded, first, sizeof first);
         if (wi != v->first.n_witness) FAIL(RSV_R_FRI_FIRST); /* folding.rs:367 */
         if (probe->pair_records) { g_pair_record = &probe->pair_records[0]; probe->n_inner = v->n_inner; probe->M = M; probe->nq = nq; memcpy(probe->qM, qM, 4 * nq); }
         int first_ok = verify_pair_tree(qM, nq, M, has_data, flat, nflat, &v->first.decommit, v->first.commitment);
@@ -1226,6 +1228,30 @@ int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* 
         }
     }
     rc = (int)o;
+done:
+    free(pr); free(v);
+    return rc;
+}
+
+/* FirstLayerHints::folded_evals_by_column (components/hints/src/folding.rs:343-360): out [3][nq][4], the circle->line
+ * fold of every query's first-layer pair at each column log size (descending), transcript query order. */
+int rsvo_fri_folded(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out, size_t cap,
+                    uint32_t* n_sizes, uint32_t* n_queries) {
+    if (!proof || !out || !n_sizes || !n_queries) return RSV_E_NULL;
+    query_probe* pr = calloc(1, sizeof *pr);
+    proof_view* v = malloc(sizeof *v);
+    int rc = RSV_OK;
+    if (!parse_proof(proof, len, NULL, v)) { rc = RSV_E_SIZE; goto done; }
+    if (verify_one(proof, len, NULL, pi, n_pi, pr) != RSV_R_OK) { rc = RSV_E_SIZE; goto done; }
+    const uint32_t nq = v->cfg.n_queries;
+    if (cap < (size_t)3 * nq * 4) { rc = RSV_E_CAP; goto done; }
+    *n_sizes = pr->n_sizes; *n_queries = nq;
+    for (uint32_t g = 0; g < 3; g++)
+        for (uint32_t j = 0; j < nq; j++) {
+            qm31 q = g < pr->n_sizes ? pr->first_folded[g][j] : Q_ZERO;
+            uint32_t* o = out + ((size_t)g * nq + j) * 4;
+            o[0] = q.a.a; o[1] = q.a.b; o[2] = q.b.a; o[3] = q.b.b;
+        }
 done:
     free(pr); free(v);
     return rc;

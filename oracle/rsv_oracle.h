@@ -60,6 +60,8 @@ int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* p
                      size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries);
 int rsvo_trace_cols(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* cols, size_t cap,
                     uint32_t* n_queries);
+int rsvo_fri_folded(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out, size_t cap,
+                    uint32_t* n_sizes, uint32_t* n_queries);
 
 /* SURVEY 8f.1, pair trees (layout: see rsv_oracle.c). */
 int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,

@@ -55,7 +55,8 @@ class PublicInput(ctypes.Structure):
 class HintsOut(ctypes.Structure):  # rsv_hints_out
     _fields_ = [("n_queries", ctypes.c_uint32), ("max_log", ctypes.c_uint32), ("n_inner", ctypes.c_uint32),
                 ("d_transcript", ctypes.c_void_p), ("d_trace_sib", ctypes.c_void_p), ("d_trace_pos", ctypes.c_void_p),
-                ("d_trace_cols", ctypes.c_void_p), ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p)]
+                ("d_trace_cols", ctypes.c_void_p), ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p),
+                ("d_fri_folded", ctypes.c_void_p)]
 
 
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
@@ -343,12 +344,12 @@ class Context:
 
     def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,
-                     d_fri_cols=None):
+                     d_fri_cols=None, d_fri_folded=None):
         """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
         shape = (n_queries, max_log, n_inner), needed for the path outputs."""
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
-                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols))
+                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded))
         pi = make_inputs(inputs)
         _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
                                         ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")

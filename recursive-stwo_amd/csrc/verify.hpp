@@ -792,6 +792,7 @@ struct QueryArgs {
     PlanPtrs pl;
     uint32_t* leafv;  // [n][3 + maxInner][G][8]
     uint32_t maxInner;
+    uint32_t* folded_out;  // optional [n][3][G][4]: first-layer folds per size group, transcript query order
 };
 
 __device__ __forceinline__ uint32_t ent_rb(uint32_t e) { return e & 0xFFu; }
@@ -912,6 +913,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
             // point (bit 0 of the position cleared) is the conjugate of this point when the position is odd
             uint32_t by = (pos & 1u) ? m_neg(dp[g].y) : dp[g].y;
             first[g] = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
+            if (a.folded_out) stq(a.folded_out + (((size_t)slot * 3 + g) * G + c->qperm[j]) * 4, first[g]);
         }
         __syncthreads();
     }

@@ -223,6 +223,22 @@ def trace_cols(proof: bytes, inputs=STANDARD_INPUTS):
     return cols[:4 * n * 64].reshape(4, n, 64).copy()
 
 
+def fri_folded(proof: bytes, inputs=STANDARD_INPUTS):
+    """-> uint32[3, nq, 4]: FirstLayerHints::folded_evals_by_column per column log size (descending) and query."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    out = np.zeros(3 * 128 * 4, np.uint32)
+    ns, nq = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    pi = make_inputs(inputs)
+    lib.rsvo_fri_folded.restype = ctypes.c_int
+    lib.rsvo_fri_folded.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p, _u32p]
+    rc = lib.rsvo_fri_folded(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), out.ctypes.data_as(_u32p), out.size,
+                             ns.ctypes.data_as(_u32p), nq.ctypes.data_as(_u32p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_fri_folded -> {rc}")
+    n = int(nq[0])
+    return out[:3 * n * 4].reshape(3, n, 4).copy()
+
+
 def fri_paths(proof: bytes, n_queries: int, max_log: int, n_trees: int, inputs=STANDARD_INPUTS):
     """-> (sib uint32[n_trees, nq, M, 8], cols uint32[n_trees, nq, 3, 8])."""
     b = np.frombuffer(proof, dtype=np.uint8)

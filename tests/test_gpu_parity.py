@@ -429,9 +429,10 @@ def test_verify_hints_one_pass(rsv, manifest):
     d_tc = torch.zeros((n, 4, nq, 64), dtype=torch.int32, device=dev)
     d_fs = torch.zeros((n, 1 + n_inner, nq, M, 8), dtype=torch.int32, device=dev)
     d_fc = torch.zeros((n, 1 + n_inner, nq, 3, 8), dtype=torch.int32, device=dev)
+    d_ff = torch.zeros((n, 3, nq, 4), dtype=torch.int32, device=dev)
     ctx = rsv.Context(0)
     ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq, M, n_inner), d_transcript=d_tr, d_trace_sib=d_ts,
-                     d_trace_pos=d_tp, d_trace_cols=d_tc, d_fri_sib=d_fs, d_fri_cols=d_fc)
+                     d_trace_pos=d_tp, d_trace_cols=d_tc, d_fri_sib=d_fs, d_fri_cols=d_fc, d_fri_folded=d_ff)
     ctx.synchronize()
     oacc, oreason = ob.verify_batch(batch)
     assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
@@ -442,6 +443,7 @@ def test_verify_hints_one_pass(rsv, manifest):
     ok = np.nonzero(oacc)[0]
     assert np.array_equal(d_ts.cpu().numpy().view(np.uint32)[ok], tsib[ok]) and np.array_equal(d_tp.cpu().numpy().view(np.uint32)[ok], tpos[ok])
     assert np.array_equal(d_fs.cpu().numpy().view(np.uint32)[ok], fsib[ok]) and np.array_equal(d_fc.cpu().numpy().view(np.uint32)[ok], fcols[ok])
+    assert np.array_equal(d_ff.cpu().numpy().view(np.uint32)[ok[0]], ob.fri_folded(proof))
     # SinglePathMerkleProof::columns, and the whole struct through the path verifier: every path -> its commitment
     tcols = d_tc.cpu().numpy().view(np.uint32)
     assert np.array_equal(tcols[ok[0]], ob.trace_cols(proof))
