@@ -233,6 +233,10 @@ typedef struct {
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,
                          uint8_t* d_reason);
+/* Same with every pointer (blob, offsets, the outputs named in *out, accept, reason) in HOST memory: the library
+ * stages them through HBM.  rsv_trace_paths, rsv_fri_paths and rsv_transcript_batch are special cases of it. */
+int rsv_verify_hints(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+                     const rsv_hints_out* out, uint8_t* accept, uint8_t* reason, int device);
 /* Host-buffer convenience for the transcript rows only (any mix of shapes): out is [n][RSV_TRANSCRIPT_WORDS]. */
 int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, uint32_t* out, int device);
 

@@ -97,6 +97,8 @@ def _load() -> ctypes.CDLL:
         "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
         "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
+        "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
+                                            ctypes.c_int]),
         "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, _u32p, ctypes.c_int]),
         "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                              ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp]),
@@ -119,7 +121,8 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
-           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_transcript_batch"]
+           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints",
+           "rsv_transcript_batch"]
 
 
 def _check(rc: int, what: str) -> None:

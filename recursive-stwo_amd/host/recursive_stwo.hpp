@@ -13,6 +13,8 @@
 //   SinglePathMerkleProof::verify          components/hints/src/decommit.rs:22-42
 //   FiatShamirResults::compute             components/recursive/fiat_shamir/src/lib.rs:31-176
 //   verify (FiatShamir → Composition → Answer → Folding)   examples/single-proof/src/main.rs:48-82
+//   hints::{DecommitHints, SinglePairMerkleProof, FirstLayerHints, InnerLayersHints}::compute
+//                                          components/hints/src/decommit.rs:186-250, folding.rs:21-91,290-601
 //
 // The reference panics (assert_eq!/unwrap, panic = 'abort') when a check fails; here a failed check
 // throws recursive_stwo::VerificationError carrying the stage, and API/device failures throw
@@ -226,6 +228,178 @@ struct FiatShamirResults {
         for (uint32_t i = 0; i < na; i++) r.fri_alphas.push_back(q(40 + 4 * i));
         r.raw_queries.assign(out.begin() + 40 + 4 * na, out.begin() + 40 + 4 * na + nq);
         return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// components/hints: what the reference derives on the host with stwo's native verifier, here read from ONE
+// verifying pass on the GPU (rsv_verify_hints).  A proof that does not verify throws VerificationError, as the
+// reference's hint constructors panic.
+// ---------------------------------------------------------------------------------------------------
+// SinglePairMerkleProof (components/hints/src/folding.rs:21-91)
+struct SinglePairMerkleProof {
+    uint32_t query = 0;
+    std::vector<Hash> sibling_hashes;
+    std::vector<std::optional<QM31>> self_columns, siblings_columns;  // indexed by level h = 0..depth
+    Hash root{};
+    uint32_t depth = 0;
+    static std::vector<M31> words(const std::optional<QM31>& q) { return q ? std::vector<M31>(q->begin(), q->end()) : std::vector<M31>{}; }
+    // pub fn verify(&self)
+    void verify() const {
+        using H = Poseidon31MerkleHasherVar;
+        HashVar self_hash = H::hash_node(nullptr, nullptr, words(self_columns[depth]));
+        HashVar sibling_hash = H::hash_node(nullptr, nullptr, words(siblings_columns[depth]));
+        for (uint32_t i = 0; i < depth; i++) {
+            const uint32_t h = depth - i - 1;
+            const bool bit = (query >> i) & 1u;
+            const HashVar& l = bit ? sibling_hash : self_hash;
+            const HashVar& r = bit ? self_hash : sibling_hash;
+            if (!self_columns[h]) {
+                self_hash = H::hash_node(&l, &r, {});
+                if (i != depth - 1) sibling_hash = HashVar::from_m31(sibling_hashes[i].data());
+            } else {
+                self_hash = H::hash_node(&l, &r, words(self_columns[h]));
+                HashVar column_hash = H::hash_m31_columns_get_capacity(words(siblings_columns[h]));
+                sibling_hash = HashVar::permute_get_rate(HashVar::from_m31(sibling_hashes[i].data()), column_hash);
+            }
+        }
+        Hash got{};
+        for (int k = 0; k < 8; k++) got[k] = self_hash.value[k];
+        if (got != root) throw VerificationError(RSV_R_FRI_FIRST);
+    }
+};
+
+struct ProofShape {  // read from the proof header
+    uint32_t lp, lq, log_blowup, log_last, n_queries, A, B, M, n_inner;
+    static ProofShape of(const std::vector<uint8_t>& proof) {
+        if (proof.size() < 64) throw VerificationError(RSV_R_PARSE);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(proof.data());
+        ProofShape s{};
+        s.lp = w[0]; s.lq = w[1]; s.log_blowup = w[11]; s.log_last = w[12]; s.n_queries = w[13];
+        if (s.lp > 24 || s.lq > 24 || s.log_blowup > 8 || s.n_queries < 4 || s.n_queries > 128) throw VerificationError(RSV_R_PARSE);
+        s.A = s.lp + s.log_blowup; s.B = s.lq + s.log_blowup;
+        s.M = (s.lp + 1 > s.lq + 2 ? s.lp + 1 : s.lq + 2) + s.log_blowup;
+        if (s.M < s.log_blowup + s.log_last + 1) throw VerificationError(RSV_R_PARSE);
+        s.n_inner = s.M - s.log_blowup - s.log_last - 1;
+        return s;
+    }
+    static uint32_t plonk_cols(int t) { return t == 0 ? 10u : t == 1 ? 12u : t == 2 ? 8u : 0u; }
+    static uint32_t poseidon_cols(int t) { return t == 0 ? 40u : t == 1 ? 48u : t == 2 ? 8u : 0u; }
+};
+
+struct Hints {
+    // FiatShamirHints (values), DecommitHints, FirstLayerHints, InnerLayersHints of one proof
+    FiatShamirResults fiat_shamir;
+    // DecommitHints (decommit.rs:186-192): precomputed / trace / interaction / composition proofs, one per query
+    std::array<std::vector<SinglePathMerkleProof>, 4> decommit;
+    // FirstLayerHints (folding.rs:290-294)
+    std::vector<SinglePairMerkleProof> first_layer_merkle_proofs;
+    std::vector<std::pair<uint32_t, std::vector<QM31>>> folded_evals_by_column;  // (column log size desc., per query)
+    // InnerLayersHints (folding.rs:454-457): per inner layer (log size M-1-i): proofs per query; the folded value of
+    // a query at that layer is the proof's self column at the leaf level
+    std::vector<std::pair<uint32_t, std::vector<SinglePairMerkleProof>>> inner_layers_merkle_proofs;
+
+    static Hints compute(const std::vector<uint8_t>& proof, const Inputs& inputs) {
+        const ProofShape sh = ProofShape::of(proof);
+        const uint32_t nq = sh.n_queries, M = sh.M, nt = 1 + sh.n_inner;
+        std::vector<uint32_t> row(RSV_TRANSCRIPT_WORDS), tsib((size_t)4 * nq * M * 8), tpos(4 * nq), tcols((size_t)4 * nq * 64),
+            fsib((size_t)nt * nq * M * 8), fcols((size_t)nt * nq * 24), ffold((size_t)3 * nq * 4);
+        rsv_hints_out ho{};
+        ho.n_queries = nq; ho.max_log = M; ho.n_inner = sh.n_inner;
+        ho.d_transcript = row.data(); ho.d_trace_sib = tsib.data(); ho.d_trace_pos = tpos.data(); ho.d_trace_cols = tcols.data();
+        ho.d_fri_sib = fsib.data(); ho.d_fri_cols = fcols.data(); ho.d_fri_folded = ffold.data();
+        const uint64_t offsets[2] = {0, proof.size()};
+        uint8_t accept = 0, reason = 0;
+        auto pi = abi_inputs(inputs);
+        int st = rsv_verify_hints(proof.data(), offsets, 1, pi.data(), pi.size(), &ho, &accept, &reason, default_device());
+        if (st == RSV_E_SIZE) throw VerificationError(RSV_R_PARSE);  // header shape and body disagree
+        check(st, "rsv_verify_hints");
+        if (!accept) throw VerificationError((rsv_reason)reason);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(proof.data());
+        Hints h;
+        auto q4 = [](const uint32_t* p) { return QM31{p[0], p[1], p[2], p[3]}; };
+        {
+            FiatShamirResults& r = h.fiat_shamir;
+            r.max_first_layer_column_log_size = row[3];
+            r.z = q4(&row[4]); r.alpha = q4(&row[8]); r.random_coeff = q4(&row[12]); r.oods_t = q4(&row[16]);
+            r.oods_x = q4(&row[20]); r.oods_y = q4(&row[24]); r.after_sampled_values_random_coeff = q4(&row[28]);
+            for (uint32_t i = 0; i < row[1]; i++) r.fri_alphas.push_back(q4(&row[40 + 4 * i]));
+            r.raw_queries.assign(row.begin() + 156, row.begin() + 156 + nq);
+        }
+        for (int t = 0; t < 4; t++) {
+            const uint32_t depth = t == 3 ? M : (sh.A > sh.B ? sh.A : sh.B);
+            for (uint32_t i = 0; i < nq; i++) {
+                SinglePathMerkleProof p;
+                p.query = tpos[t * nq + i];
+                p.depth = depth;
+                for (int k = 0; k < 8; k++) p.root[k] = w[17 + 8 * t + k];
+                for (uint32_t k = 0; k < depth; k++) {
+                    Hash hh;
+                    for (int e = 0; e < 8; e++) hh[e] = tsib[(((size_t)t * nq + i) * M + k) * 8 + e];
+                    p.sibling_hashes.push_back(hh);
+                }
+                p.columns.assign(depth + 1, {});
+                const uint32_t* c = &tcols[((size_t)t * nq + i) * 64];
+                if (t == 3) p.columns[M].assign(c, c + 8);
+                else {
+                    // leaf-level columns first, then the lower log size; at equal sizes plonk columns precede poseidon's
+                    const uint32_t hi = depth, lo = sh.A < sh.B ? sh.A : sh.B;
+                    uint32_t n_hi = (sh.A == hi ? ProofShape::plonk_cols(t) : 0) + (sh.B == hi ? ProofShape::poseidon_cols(t) : 0);
+                    p.columns[hi].assign(c, c + n_hi);
+                    if (lo != hi) p.columns[lo].assign(c + n_hi, c + n_hi + (sh.A == lo ? ProofShape::plonk_cols(t) : ProofShape::poseidon_cols(t)));
+                }
+                h.decommit[t].push_back(std::move(p));
+            }
+        }
+        // column log sizes of the first layer, descending
+        std::vector<uint32_t> sizes{M};
+        if (sh.A == sh.B) sizes.push_back(sh.A);
+        else { sizes.push_back(sh.A > sh.B ? sh.A : sh.B); sizes.push_back(sh.A < sh.B ? sh.A : sh.B); }
+        auto pair_proof = [&](uint32_t s, uint32_t i, uint32_t depth, const std::vector<uint32_t>& data_levels, const uint32_t* root) {
+            SinglePairMerkleProof p;
+            p.query = (h.fiat_shamir.raw_queries[i] & ((1u << M) - 1u)) >> (M - depth);
+            p.depth = depth;
+            for (int k = 0; k < 8; k++) p.root[k] = root[k];
+            for (uint32_t k = 0; k + 1 < depth; k++) {
+                Hash hh;
+                for (int e = 0; e < 8; e++) hh[e] = fsib[(((size_t)s * nq + i) * M + k) * 8 + e];
+                p.sibling_hashes.push_back(hh);
+            }
+            p.self_columns.assign(depth + 1, std::nullopt);
+            p.siblings_columns.assign(depth + 1, std::nullopt);
+            for (size_t c = 0; c < data_levels.size(); c++) {
+                const uint32_t* v = &fcols[(((size_t)s * nq + i) * 3 + c) * 8];
+                p.self_columns[data_levels[c]] = q4(v);
+                p.siblings_columns[data_levels[c]] = q4(v + 4);
+            }
+            return p;
+        };
+        // FRI layer commitments: walk the variable part
+        std::vector<const uint32_t*> commitments;
+        {
+            size_t pos = 895 + 2;
+            for (int t = 0; t < 4; t++) { pos += 2 + 8 * (size_t)w[pos] + 2; }
+            pos += 2;
+            for (int t = 0; t < 4; t++) { pos += 2 + (size_t)w[pos]; }
+            pos += 2;
+            auto layer = [&](size_t at) { at += 2 + 4 * (size_t)w[at]; at += 2 + 8 * (size_t)w[at] + 2; commitments.push_back(w + at); return at + 8; };
+            pos = layer(pos);
+            const uint32_t n_inner = w[pos]; pos += 2;
+            for (uint32_t i = 0; i < n_inner; i++) pos = layer(pos);
+        }
+        for (uint32_t i = 0; i < nq; i++) h.first_layer_merkle_proofs.push_back(pair_proof(0, i, M, sizes, commitments[0]));
+        for (size_t g = 0; g < sizes.size(); g++) {
+            std::vector<QM31> v;
+            for (uint32_t i = 0; i < nq; i++) v.push_back(q4(&ffold[((size_t)g * nq + i) * 4]));
+            h.folded_evals_by_column.push_back({sizes[g], std::move(v)});
+        }
+        for (uint32_t l = 0; l < sh.n_inner; l++) {
+            const uint32_t depth = M - 1 - l;
+            std::vector<SinglePairMerkleProof> v;
+            for (uint32_t i = 0; i < nq; i++) v.push_back(pair_proof(1 + l, i, depth, {depth}, commitments[1 + l]));
+            h.inner_layers_merkle_proofs.push_back({depth, std::move(v)});
+        }
+        return h;
     }
 };
 

@@ -110,6 +110,42 @@ static void test_verify(const std::vector<uint8_t>& small) {
     EXPECT(acc[0] == 1 && acc[1] == 0 && reason[1] != 0);
 }
 
+// components/hints/src/decommit.rs test_decommitment + folding.rs test_folding: derive the hints of small_proof.bin
+// and verify every per-query path against its commitment.
+static void test_hints(const std::vector<uint8_t>& small) {
+    Inputs inputs = {{1, QM31{1, 0, 0, 0}}};
+    Hints h = Hints::compute(small, inputs);
+    EXPECT((h.fiat_shamir.z == QM31{1211683141, 437669427, 409200369, 1127771350}));
+    EXPECT(h.fiat_shamir.raw_queries.size() == 16);
+    for (int t = 0; t < 4; t++) {
+        EXPECT(h.decommit[t].size() == 16);
+        for (const auto& p : h.decommit[t]) p.verify();  // throws on a root mismatch
+    }
+    EXPECT(h.first_layer_merkle_proofs.size() == 16);
+    for (const auto& p : h.first_layer_merkle_proofs) p.verify();
+    EXPECT(h.folded_evals_by_column.size() == 3 && h.folded_evals_by_column[0].first == 15);
+    EXPECT(h.inner_layers_merkle_proofs.size() == 7);
+    for (const auto& layer : h.inner_layers_merkle_proofs) {
+        EXPECT(layer.second.size() == 16 && layer.second[0].depth == layer.first);
+        for (size_t i = 0; i < layer.second.size(); i += 5) layer.second[i].verify();
+    }
+    // a tampered sibling hash must fail the path it belongs to
+    auto bad = h.decommit[2][3];
+    bad.sibling_hashes[4][0] ^= 1;
+    bool threw = false;
+    try { bad.verify(); } catch (const VerificationError&) { threw = true; }
+    EXPECT(threw);
+    auto badp = h.first_layer_merkle_proofs[1];
+    (*badp.siblings_columns[15])[2] ^= 1;
+    threw = false;
+    try { badp.verify(); } catch (const VerificationError&) { threw = true; }
+    EXPECT(threw);
+    // wrong public input: the hints constructor "panics" at the logup check
+    threw = false;
+    try { Hints::compute(small, {{1, QM31{2, 0, 0, 0}}}); } catch (const VerificationError& e) { threw = e.reason == RSV_R_LOGUP; }
+    EXPECT(threw);
+}
+
 int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "tests/golden/proofs";
     auto small = read_file(dir + "/small_proof.bin");
@@ -118,6 +154,7 @@ int main(int argc, char** argv) {
     test_channel(small);
     test_fiat_shamir(small);
     test_verify(small);
+    test_hints(small);
     printf("host mirror: all tests passed\n");
     return 0;
 }
