@@ -172,6 +172,16 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
                          size_t n, const rsv_pcs_config* cfg, const rsv_public_input* pi,
                          size_t n_pi, uint8_t* d_accept, uint8_t* d_reason);
 
+/* Proofs that start in HOST memory, as the reference's callers hold them: one serialized buffer per proof
+ * (bincode::serialize(&proof) -> Vec<u8>, examples/multi-proofs/src/main.rs:69-139).  Chunks of about
+ * RSV_HOST_CHUNK_MB (env, default 256) MB are gathered into pinned staging memory by worker threads
+ * (RSV_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
+ * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  lens[i] must be a
+ * multiple of 4 (every proof of this type is), else RSV_E_SIZE. */
+int rsv_verify_batch_host(rsv_ctx* ctx, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
+                          const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
+                          uint8_t* reason);
+
 /* ---- SURVEY 8f.1 (next row): per-query authentication paths -----------------
  * Emits, while verifying, the per-query Merkle paths of the four commitment trees in TRANSCRIPT query order —
  * the data SinglePathMerkleProof::from_stwo_proof (components/hints/src/decommit.rs:44-183) derives on the host

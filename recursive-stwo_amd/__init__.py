@@ -97,6 +97,8 @@ def _load() -> ctypes.CDLL:
         "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
         "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
+        "rsv_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(PcsConfig),
+                                                 ctypes.POINTER(PublicInput), sz, _u8p, _u8p]),
         "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
                                             ctypes.c_int]),
         "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, _u32p, ctypes.c_int]),
@@ -121,7 +123,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
-           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints",
+           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host",
            "rsv_transcript_batch"]
 
 
@@ -344,6 +346,21 @@ class Context:
         _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
                                        n_queries, max_log, d_sib.data_ptr(), d_pos.data_ptr(), d_accept.data_ptr(),
                                        d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
+
+    def verify_batch_host(self, proofs, inputs=STANDARD_INPUTS, cfg=None):
+        """Proofs in host memory, one buffer each (bytes / numpy uint8 arrays): gather, upload and verify overlap
+        (rsv_verify_batch_host).  Returns (accept, reason) numpy arrays."""
+        n = len(proofs)
+        keep = [np.frombuffer(p, dtype=np.uint8) if not isinstance(p, np.ndarray) else p for p in proofs]
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.ctypes.data for k in keep])
+        lens = np.array([k.size for k in keep], dtype=np.uint64)
+        accept = np.zeros(n, np.uint8)
+        reason = np.zeros(n, np.uint8)
+        pi = make_inputs(inputs)
+        c = ctypes.byref(cfg) if cfg is not None else None
+        _check(lib.rsv_verify_batch_host(self._h, ptrs, lens.ctypes.data_as(_u64p), n, c, pi, len(list(inputs)),
+                                         accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p)), "rsv_verify_batch_host")
+        return accept, reason
 
     def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,

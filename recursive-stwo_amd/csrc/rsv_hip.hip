@@ -11,7 +11,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "primitives.hpp"
@@ -31,6 +35,8 @@ using namespace rsv;
 namespace {
 struct VerifyState;                       // stage clock of the last verify call (verify_api.inc)
 void destroy_verify_state(VerifyState*);
+struct HostPipe;                          // pinned staging ring of rsv_verify_batch_host (host_stream.inc)
+void destroy_host_pipe(HostPipe*);
 }  // namespace
 
 struct rsv_ctx {
@@ -48,6 +54,7 @@ struct rsv_ctx {
     VerifyState* vs = nullptr;
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
+    HostPipe* host_pipe = nullptr;
 };
 
 namespace {
@@ -117,6 +124,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_query) (void)hipEventDestroy(c->ev_query);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
+    if (c->host_pipe) destroy_host_pipe(c->host_pipe);
     if (c->ws) (void)hipFree(c->ws);
     if (c->ws_fixed) (void)hipFree(c->ws_fixed);
     if (c->ws_rows) (void)hipFree(c->ws_rows);
@@ -282,3 +290,4 @@ int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint
 }  // extern "C"
 
 #include "verify_api.inc"
+#include "host_stream.inc"

@@ -403,22 +403,41 @@ struct Hints {
     }
 };
 
+// One rsv_ctx per host thread (the reference's types are !Send): keeps the HBM workspace and the pinned staging ring
+// alive between calls.
+inline rsv_ctx* thread_context() {
+    struct Holder {
+        rsv_ctx* c = nullptr;
+        int device = -1;
+        ~Holder() { if (c) rsv_ctx_destroy(c); }
+    };
+    thread_local Holder h;
+    if (!h.c || h.device != default_device()) {
+        if (h.c) rsv_ctx_destroy(h.c);
+        h.c = nullptr;
+        check(rsv_ctx_create(default_device(), &h.c), "rsv_ctx_create");
+        h.device = default_device();
+    }
+    return h.c;
+}
+
 // The whole stage sequence of examples/single-proof/src/main.rs:48-82 on a batch.
 struct Verifier {
     // accept[i] / reason[i] per proof; never throws for a bad proof.
     static void verify_batch(const std::vector<std::vector<uint8_t>>& proofs, const std::optional<PcsConfig>& config,
                              const Inputs& inputs, std::vector<uint8_t>& accept, std::vector<uint8_t>& reason) {
-        std::vector<uint8_t> blob;
-        std::vector<uint64_t> offsets{0};
-        for (auto& p : proofs) { blob.insert(blob.end(), p.begin(), p.end()); offsets.push_back(blob.size()); }
+        // one buffer per proof, as the reference holds them: the library gathers, uploads and verifies in a pipeline
+        std::vector<const uint8_t*> ptrs;
+        std::vector<uint64_t> lens;
+        for (auto& p : proofs) { ptrs.push_back(p.data()); lens.push_back(p.size()); }
         accept.assign(proofs.size(), 0);
         reason.assign(proofs.size(), 0);
         auto pi = abi_inputs(inputs);
         rsv_pcs_config cfg{};
         if (config) cfg = config->abi();
-        check(rsv_verify_batch(blob.data(), offsets.data(), proofs.size(), config ? &cfg : nullptr, pi.data(), pi.size(),
-                               accept.data(), reason.data(), default_device()),
-              "rsv_verify_batch");
+        check(rsv_verify_batch_host(thread_context(), ptrs.data(), lens.data(), proofs.size(), config ? &cfg : nullptr, pi.data(),
+                                    pi.size(), accept.data(), reason.data()),
+              "rsv_verify_batch_host");
     }
     // Reference behaviour for one proof: returns on success, "panics" (throws) at the failing stage.
     static void verify(const std::vector<uint8_t>& proof, const PcsConfig& config, const Inputs& inputs) {

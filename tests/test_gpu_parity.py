@@ -463,3 +463,26 @@ def test_verify_hints_one_pass(rsv, manifest):
     with pytest.raises(rsv.RsvError):
         ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq + 1, M, n_inner), d_trace_sib=d_ts, d_trace_pos=d_tp)
     ctx.close()
+
+
+@pytest.mark.parametrize("chunk_mb", ["1", "256"])
+def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
+    """rsv_verify_batch_host: one host buffer per proof, gather -> upload -> verify pipelined over chunks.  A 1 MB
+    chunk size forces dozens of chunks through the three-slot ring; verdicts == oracle's, in input order."""
+    monkeypatch.setenv("RSV_HOST_CHUNK_MB", chunk_mb)
+    proofs = []
+    for e in manifest:
+        pr = read_proof(e["file"])
+        if entry_inputs(e) == list(rsv.STANDARD_INPUTS):
+            proofs += [pr, ob.tamper(pr, len(proofs)), pr]
+    proofs += [read_proof("hybrid_hash.bin"), b"\x00" * 64, b""]
+    ctx = rsv.Context(0)
+    acc, reason = ctx.verify_batch_host(proofs)
+    oacc, oreason = ob.verify_batch(proofs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    assert int(acc.sum()) > 10
+    # misaligned length is an API error
+    with pytest.raises(rsv.RsvError):
+        ctx.verify_batch_host([b"\x00" * 6])
+    assert ctx.verify_batch_host([])[0].size == 0
+    ctx.close()
