@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "librsv_oracle.so")
+LIB = os.environ.get("RSV_ORACLE_LIB") or os.path.join(ROOT, "oracle", "librsv_oracle.so")  # override: sanitizer build
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _u32p = ctypes.POINTER(ctypes.c_uint32)

@@ -486,3 +486,19 @@ def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
         ctx.verify_batch_host([b"\x00" * 6])
     assert ctx.verify_batch_host([])[0].size == 0
     ctx.close()
+
+
+def test_mutant_corpus_matches_oracle(rsv, manifest):
+    """Parity fuzz: structural mutants, every length prefix perturbed, random byte corruption and truncations of
+    six fixtures of different shapes (n_queries 8..80) in ONE mixed batch: verdict and reason == oracle's."""
+    from tests.mutants import mutants_of
+    rng = np.random.default_rng(5)
+    batch = []
+    for name in ("recursive_proof_16_15.bin", "level1-5.bin", "level5-1.bin", "level8-1.bin", "level10-1.bin", "level13-1.bin"):
+        proof = read_proof(name)
+        batch += mutants_of(proof, rng, 60) + [proof]
+    acc, reason = rsv.verify_batch(batch)
+    oacc, oreason = ob.verify_batch(batch)
+    diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
+    assert diff.size == 0, [(int(i), int(reason[i]), int(oreason[i])) for i in diff[:10]]
+    assert int(acc.sum()) >= 6

@@ -1,6 +1,8 @@
 """CPU tests of the oracle against the reference's own known answers:
 the literal Poseidon2 KAT, the hasher/channel/transcript checkpoints of SURVEY App. C and the
 accept/reject behaviour of every proof fixture under the config written in the reference source."""
+import sys
+
 import numpy as np
 import pytest
 
@@ -299,3 +301,21 @@ def test_trace_paths_with_columns_recompute_all_four_roots(name):
         roots = ob.merkle_path_root(pos[t], sib[t][:, :d, :], cols[t][:, :tot], n_cols_at)
         want = words[17 + 8 * t:25 + 8 * t]
         assert all(r.tolist() == want.tolist() for r in roots), t
+
+
+def test_oracle_is_clean_under_sanitizers():
+    """The oracle's C source built with AddressSanitizer + UBSan (oracle/Makefile `asan`) runs the mutant corpus
+    (tests/mutants.py) of three fixtures without a report.  CPU only — GPU sanitizers are not available."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not installed")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               RSV_ORACLE_LIB=os.path.join(root, "oracle", "librsv_oracle_asan.so"))
+    out = subprocess.run([sys.executable, "-m", "tests.mutants", "small_proof.bin", "level12-1.bin", "level2-1.bin"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "librsv_oracle_asan.so" in out.stdout
