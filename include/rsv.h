@@ -121,6 +121,28 @@ int rsv_merkle_hash_node(const uint32_t* left8, const uint32_t* right8,
                          const uint32_t* cols, size_t n_cols, uint32_t* out8,
                          size_t n, int device);
 
+/* ---- a1 / a2 / a8 / last layer of a12: arithmetic probes ------------------------
+ * The device functions the verify kernels are built from, exposed one lane per item so that a binding (and the
+ * parity tests) can check them in isolation.  Elements are QM31 = 4 words (a0, a1, b0, b1) = (a0 + a1 i) +
+ * (b0 + b1 i) u, all canonical (else RSV_E_RANGE).
+ *   RSV_F_QADD/QSUB/QMUL  out = a (+,-,*) b                    primitives/fields/src/qm31.rs:87-249
+ *   RSV_F_QINV            out = 1/a                            qm31.rs:360-366
+ *   RSV_F_MMUL / MINV     first word only: a0*b0, 1/a0         primitives/fields/src/m31.rs:62-115,140-156
+ *   RSV_F_CMUL / CINV     first two words: CM31 product, 1/a   primitives/fields/src/cm31.rs:87-192
+ *   RSV_F_QMULI / QMULU   a*i, a*u                             qm31.rs:402-418
+ *   RSV_F_QPOW            a ^ (first word of b, any u32)       qm31.rs (QM31Var::pow; test :489)
+ * b4 may be NULL for the unary operations. */
+enum { RSV_F_QADD = 0, RSV_F_QSUB, RSV_F_QMUL, RSV_F_QINV, RSV_F_MMUL, RSV_F_MINV, RSV_F_CMUL, RSV_F_CINV,
+       RSV_F_QMULI, RSV_F_QMULU, RSV_F_QPOW };
+int rsv_field_op(int op, const uint32_t* a4, const uint32_t* b4, uint32_t* out4, size_t n, int device);
+/* a8: xy[2i], xy[2i+1] = CanonicCoset(log_size).circle_domain().at(bit_reverse(q[i], log_size)) — the point
+ * PointCarryingQueryVar carries for position q[i] (primitives/query/src/lib.rs:57-168, circle/src/lib.rs:44-131;
+ * reference test circle/src/lib.rs:264).  q[i] is masked to log_size bits; 1 <= log_size <= 30. */
+int rsv_domain_points(uint32_t log_size, const uint32_t* q, uint32_t* xy, size_t n, int device);
+/* LinePolyVar::eval_at_point (primitives/line/src/lib.rs:39-67; reference test :82): one polynomial of 2^log_n
+ * QM31 coefficients (log_n <= 16) evaluated at n points x[i] (M31). */
+int rsv_line_eval(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, uint32_t* out4, size_t n, int device);
+
 /* ---- a9: one authentication path per query --------------------------------
  * Replaces SinglePathMerkleProofVar::verify
  * (components/recursive/data_structures/src/lib.rs:315-354).

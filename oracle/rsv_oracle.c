@@ -977,6 +977,44 @@ static qm31 line_fold(const uint32_t* coeffs, uint64_t n, const m31* factors) {
     return q_add(l, q_mul_m(r, factors[0]));
 }
 
+/* probes with the op codes of include/rsv.h (RSV_F_*) */
+int rsvo_field_op(int op, const uint32_t* a4, const uint32_t* b4, uint32_t* out4, size_t n) {
+    if (n && (!a4 || !out4)) return RSV_E_NULL;
+    for (size_t i = 0; i < n; i++) {
+        qm31 x = q_mk(a4[4 * i], a4[4 * i + 1], a4[4 * i + 2], a4[4 * i + 3]);
+        qm31 y = b4 ? q_mk(b4[4 * i], b4[4 * i + 1], b4[4 * i + 2], b4[4 * i + 3]) : Q_ZERO, r = Q_ZERO;
+        switch (op) {
+            case 0: r = q_add(x, y); break;
+            case 1: r = q_sub(x, y); break;
+            case 2: r = q_mul(x, y); break;
+            case 3: r = q_inv(x); break;
+            case 4: r = q_mk(m_mul(x.a.a, y.a.a), 0, 0, 0); break;
+            case 5: r = q_mk(m_inv(x.a.a), 0, 0, 0); break;
+            case 6: { cm31 c = c_mul(x.a, y.a); r = q_mk(c.a, c.b, 0, 0); } break;
+            case 7: { cm31 c = c_inv(x.a); r = q_mk(c.a, c.b, 0, 0); } break;
+            case 8: { const qm31 I = {{0, 1}, {0, 0}}; r = q_mul(x, I); } break;
+            case 9: { const qm31 U = {{0, 0}, {1, 0}}; r = q_mul(x, U); } break;
+            case 10: { /* square-and-multiply from the top bit, unlike the GPU's bottom-up loop */
+                r = q_mk(1, 0, 0, 0);
+                for (int bit = 31; bit >= 0; bit--) { r = q_mul(r, r); if ((y.a.a >> bit) & 1u) r = q_mul(r, x); }
+            } break;
+            default: return RSV_E_SIZE;
+        }
+        out4[4 * i] = r.a.a; out4[4 * i + 1] = r.a.b; out4[4 * i + 2] = r.b.a; out4[4 * i + 3] = r.b.b;
+    }
+    return RSV_OK;
+}
+int rsvo_line_eval(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, uint32_t* out4, size_t n) {
+    if (!coeffs4 || (n && (!x || !out4)) || log_n > 16) return RSV_E_NULL;
+    for (size_t i = 0; i < n; i++) {
+        m31 d[32], v = x[i];
+        for (uint32_t k = 0; k < log_n; k++) { d[k] = v; v = m_sub(m_add(m_mul(v, v), m_mul(v, v)), 1); }
+        qm31 r = line_fold(coeffs4, (uint64_t)1 << log_n, d);
+        out4[4 * i] = r.a.a; out4[4 * i + 1] = r.a.b; out4[4 * i + 2] = r.b.a; out4[4 * i + 3] = r.b.b;
+    }
+    return RSV_OK;
+}
+
 typedef struct {
     /* per query j (transcript order) */
     qm31 answers[3][MAX_QUERIES];

@@ -46,6 +46,8 @@ void rsvo_qm31_mul(const uint32_t* a, const uint32_t* b, uint32_t* out);
 void rsvo_qm31_inv(const uint32_t* a, uint32_t* out);
 /* CanonicCoset(log).circle_domain().at(bit_reverse(q, log)) -> (x, y). */
 void rsvo_domain_point(uint32_t log_size, uint32_t q, uint32_t* xy);
+int rsvo_field_op(int op, const uint32_t* a4, const uint32_t* b4, uint32_t* out4, size_t n);
+int rsvo_line_eval(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, uint32_t* out4, size_t n);
 /* Per-query intermediate values of one proof (for kernel-level parity tests):
  * out receives, for every query j in transcript order, the DEEP-quotient
  * answers for the distinct column log sizes in descending order

@@ -97,6 +97,9 @@ def _load() -> ctypes.CDLL:
         "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
         "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
+        "rsv_field_op": (ctypes.c_int, [ctypes.c_int, _u32p, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_domain_points": (ctypes.c_int, [ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_line_eval": (ctypes.c_int, [_u32p, ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(PcsConfig),
                                                  ctypes.POINTER(PublicInput), sz, _u8p, _u8p]),
         "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
@@ -123,7 +126,8 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
-           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host",
+           "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
+           "rsv_line_eval",
            "rsv_transcript_batch"]
 
 
@@ -163,6 +167,41 @@ def poseidon2_permute(states, device: int = 0) -> np.ndarray:
     out = np.empty_like(s)
     _check(lib.rsv_poseidon2_permute(s.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), s.shape[0], device),
            "rsv_poseidon2_permute")
+    return out
+
+
+F_QADD, F_QSUB, F_QMUL, F_QINV, F_MMUL, F_MINV, F_CMUL, F_CINV, F_QMULI, F_QMULU, F_QPOW = range(11)  # RSV_F_*
+
+
+def field_op(op: int, a, b=None, device: int = 0) -> np.ndarray:
+    """Batched M31 / CM31 / QM31 arithmetic probe (rsv_field_op): a, b are (n, 4) QM31 words."""
+    x = _u32(a).reshape(-1, 4)
+    y = None if b is None else _u32(b).reshape(-1, 4)
+    out = np.empty_like(x)
+    _check(lib.rsv_field_op(op, x.ctypes.data_as(_u32p), None if y is None else y.ctypes.data_as(_u32p),
+                            out.ctypes.data_as(_u32p), x.shape[0], device), "rsv_field_op")
+    return out
+
+
+def domain_points(log_size: int, q, device: int = 0) -> np.ndarray:
+    """(n, 2) circle-domain points of the query positions q at log_size (rsv_domain_points)."""
+    qq = _u32(q).reshape(-1)
+    out = np.empty((qq.size, 2), np.uint32)
+    _check(lib.rsv_domain_points(log_size, qq.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), qq.size, device),
+           "rsv_domain_points")
+    return out
+
+
+def line_eval(coeffs, x, device: int = 0) -> np.ndarray:
+    """LinePolyVar::eval_at_point of one polynomial (2^k QM31 coefficients) at the points x: (n, 4)."""
+    c = _u32(coeffs).reshape(-1, 4)
+    log_n = int(c.shape[0]).bit_length() - 1
+    if c.shape[0] != 1 << log_n:
+        raise ValueError("coefficient count must be a power of two")
+    xx = _u32(x).reshape(-1)
+    out = np.empty((xx.size, 4), np.uint32)
+    _check(lib.rsv_line_eval(c.ctypes.data_as(_u32p), log_n, xx.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), xx.size,
+                             device), "rsv_line_eval")
     return out
 
 

@@ -807,6 +807,41 @@ __device__ inline QM31 fold_pair(QM31 self, QM31 sib, bool odd, uint32_t inv_coo
     return q_add(q_add(l, r), q_mul(q_mul_m(q_sub(l, r), inv_coord), alpha));
 }
 
+// LinePolyVar::eval_at_point (primitives/line/src/lib.rs:39-67): fold(coeffs, [x, pi(x), pi(pi(x)), ...]) with
+// fold(v, [f, rest]) = fold(v_lo, rest) + f * fold(v_hi, rest), i.e. sum_i coeff_i * prod_k d[k]^(bit (log_n-1-k) of i).
+// The weights factor into a table over the low 4 index bits (registers) times a product over the high bits.
+// cf: n = 2^log_n QM31 coefficients (4 words each).
+__device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x) {
+    uint32_t d[16];
+    for (uint32_t k = 0; k < 16; k++) { d[k] = (k < log_n) ? x : 1u; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+    const uint32_t nlo = log_n < 4 ? log_n : 4u;
+    uint32_t wl[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) wl[t] = 1u;
+    // low index bit b pairs with d[log_n - 1 - b]
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        uint32_t db = (uint32_t)b < nlo ? d[(log_n - 1 - b) & 15u] : 1u;
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (t & (1 << b)) wl[t] = m_mul(wl[t], db);
+    }
+    QM31 acc = q_zero();
+    const uint32_t n_hi = n >> nlo, n_lo = 1u << nlo;
+#pragma unroll 1
+    for (uint32_t hi = 0; hi < n_hi; hi++) {
+        uint32_t wh = 1u;
+        for (uint32_t b = 0; b + nlo < log_n; b++)
+            if ((hi >> b) & 1u) wh = m_mul(wh, d[(log_n - 1 - nlo - b) & 15u]);
+        QM31 inner = q_zero();
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if ((uint32_t)t < n_lo) inner = q_add(inner, q_mul_m(ldq(cf + 4 * ((hi << nlo) + t)), wl[t]));
+        acc = q_add(acc, q_mul_m(inner, wh));
+    }
+    return acc;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     __shared__ uint32_t xq[BLOCK][4];
@@ -958,41 +993,55 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     // ---- last layer (folding/src/lib.rs:194-204, primitives/line/src/lib.rs:39-67)
     if (live) {
         // x of half_odds(l-1).at(bit_reverse(pos >> 1)) = pi(X_l) (for a proof without inner layers: pi of x_M)
-        uint32_t x = m_sub(m_dbl(m_sqr(X)), 1u);
-        const uint32_t log_n = m->log_last;
-        // fold(coeffs, [x, pi(x), ...]) = sum_i coeff_i * prod_k d[k]^(bit (log_n-1-k) of i).  The weights
-        // factor into a table over the low 4 index bits (registers) times a product over the high bits.
-        uint32_t d[16];
-        for (uint32_t k = 0; k < 16; k++) { d[k] = (k < log_n) ? x : 1u; x = m_sub(m_dbl(m_sqr(x)), 1u); }
-        const uint32_t nlo = log_n < 4 ? log_n : 4u;
-        uint32_t wl[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) wl[t] = 1u;
-        // low index bit b pairs with d[log_n - 1 - b]
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            uint32_t db = (uint32_t)b < nlo ? d[(log_n - 1 - b) & 15u] : 1u;
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-                if (t & (1 << b)) wl[t] = m_mul(wl[t], db);
-        }
-        QM31 acc = q_zero();
-        const uint32_t* cf = w + m->last_off;
-        const uint32_t n_hi = m->last_n >> nlo, n_lo = 1u << nlo;
-#pragma unroll 1
-        for (uint32_t hi = 0; hi < n_hi; hi++) {
-            uint32_t wh = 1u;
-            for (uint32_t b = 0; b + nlo < log_n; b++)
-                if ((hi >> b) & 1u) wh = m_mul(wh, d[(log_n - 1 - nlo - b) & 15u]);
-            QM31 inner = q_zero();
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-                if ((uint32_t)t < n_lo) inner = q_add(inner, q_mul_m(ldq(cf + 4 * ((hi << nlo) + t)), wl[t]));
-            acc = q_add(acc, q_mul_m(inner, wh));
-        }
+        QM31 acc = line_eval(w + m->last_off, m->log_last, m->last_n, m_sub(m_dbl(m_sqr(X)), 1u));
         if (!q_eq(acc, folded)) flags |= 1u << R_FRI_LAST;
     }
     if (flags) atomicOr(&c->flags, flags);
+}
+
+// ------------------------------------------------------------------ probes
+// Batch probes of the arithmetic the verify kernels are made of (include/rsv.h: rsv_field_op, rsv_domain_points,
+// rsv_line_eval): the SAME device functions, one lane per item, so that each can be checked on its own
+// (SURVEY rows a1, a2, a8 and the last layer of a12).
+__global__ __launch_bounds__(256) void k_field_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                   uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    QM31 x = ldq(a + 4 * i), y = b ? ldq(b + 4 * i) : q_zero(), r = q_zero();
+    switch (op) {
+        case 0: r = q_add(x, y); break;
+        case 1: r = q_sub(x, y); break;
+        case 2: r = q_mul(x, y); break;
+        case 3: r = q_inv(x); break;
+        case 4: r = q_mk(m_mul(x.a.a, y.a.a), 0, 0, 0); break;           // M31 product of the first words
+        case 5: r = q_mk(m_inv(x.a.a), 0, 0, 0); break;                  // M31 inverse of the first word
+        case 6: { CM31 c = c_mul(x.a, y.a); r = q_mk(c.a, c.b, 0, 0); } break;
+        case 7: { CM31 c = c_inv(x.a); r = q_mk(c.a, c.b, 0, 0); } break;
+        case 8: r = q_mul_i(x); break;
+        case 9: r = q_mul_u(x); break;
+        case 10: {                                                       // x^e, e = first word of y (QM31Var::pow)
+            QM31 acc = q_one(), base = x;
+            for (uint32_t e = y.a.a; e; e >>= 1) { if (e & 1u) acc = q_mul(acc, base); base = q_mul(base, base); }
+            r = acc;
+        } break;
+        default: break;
+    }
+    stq(out + 4 * i, r);
+}
+
+__global__ __launch_bounds__(256) void k_domain_points(uint32_t log_size, const uint32_t* __restrict__ q,
+                                                        uint32_t* __restrict__ xy, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    CPoint p = domain_point(log_size, q[i] & ((1u << log_size) - 1u));
+    xy[2 * i] = p.x; xy[2 * i + 1] = p.y;
+}
+
+__global__ __launch_bounds__(256) void k_line_eval(const uint32_t* __restrict__ coeffs, uint32_t log_n,
+                                                    const uint32_t* __restrict__ x, uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    stq(out + 4 * i, line_eval(coeffs, log_n, 1u << log_n, x[i]));
 }
 
 // --------------------------------------------------------------- k_row_hash

@@ -174,6 +174,34 @@ def domain_point(log_size, q):
     return int(out[0]), int(out[1])
 
 
+def field_op(op, a, b=None):
+    x = _u32(a).reshape(-1, 4)
+    y = None if b is None else _u32(b).reshape(-1, 4)
+    out = np.empty_like(x)
+    lib.rsvo_field_op.restype = ctypes.c_int
+    lib.rsvo_field_op.argtypes = [ctypes.c_int, _u32p, _u32p, _u32p, ctypes.c_size_t]
+    rc = lib.rsvo_field_op(op, x.ctypes.data_as(_u32p), None if y is None else y.ctypes.data_as(_u32p),
+                           out.ctypes.data_as(_u32p), x.shape[0])
+    assert rc == 0, rc
+    return out
+
+
+def domain_points(log_size, q):
+    return np.array([domain_point(log_size, int(v) & ((1 << log_size) - 1)) for v in np.asarray(q).reshape(-1)], np.uint32)
+
+
+def line_eval(coeffs, x):
+    c = _u32(coeffs).reshape(-1, 4)
+    log_n = int(c.shape[0]).bit_length() - 1
+    xx = _u32(x).reshape(-1)
+    out = np.empty((xx.size, 4), np.uint32)
+    lib.rsvo_line_eval.restype = ctypes.c_int
+    lib.rsvo_line_eval.argtypes = [_u32p, ctypes.c_uint32, _u32p, _u32p, ctypes.c_size_t]
+    rc = lib.rsvo_line_eval(c.ctypes.data_as(_u32p), log_n, xx.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), xx.size)
+    assert rc == 0, rc
+    return out
+
+
 def splitmix64(seed, i):
     """splitmix64 stream used for seeded tampering."""
     mask = (1 << 64) - 1

@@ -502,3 +502,45 @@ def test_mutant_corpus_matches_oracle(rsv, manifest):
     diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
     assert diff.size == 0, [(int(i), int(reason[i]), int(oreason[i])) for i in diff[:10]]
     assert int(acc.sum()) >= 6
+
+
+def test_field_ops_match_oracle(rsv):
+    """Rows a1/a2 on their own: every RSV_F_* operation on 2^16 random elements plus edge values == oracle."""
+    rng = np.random.default_rng(21)
+    n = 1 << 16
+    a = rng.integers(0, P, (n, 4), dtype=np.uint32)
+    b = rng.integers(0, P, (n, 4), dtype=np.uint32)
+    edge = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [P - 1] * 4, [0, 0, 1, 0], [0, 1, 0, 0], [P - 1, 0, 0, 0], [0, 0, 0, 1]], np.uint32)
+    a[:7], b[:7] = edge, edge[::-1]
+    for op in range(10):
+        bb = b if op in (0, 1, 2, 4, 6) else None
+        assert np.array_equal(rsv.field_op(op, a, bb), ob.field_op(op, a, bb)), op
+    e = np.zeros((256, 4), np.uint32)
+    e[:, 0] = rng.integers(0, 1 << 32, 256, dtype=np.uint64).astype(np.uint32)
+    e[:4, 0] = [0, 1, 2, 0xFFFFFFFF]
+    assert np.array_equal(rsv.field_op(rsv.F_QPOW, a[:256], e), ob.field_op(10, a[:256], e))
+    with pytest.raises(rsv.RsvError):
+        rsv.field_op(rsv.F_QMUL, [[P, 0, 0, 0]], [[1, 0, 0, 0]])
+    assert rsv.field_op(rsv.F_QMUL, np.zeros((0, 4), np.uint32), np.zeros((0, 4), np.uint32)).shape == (0, 4)
+
+
+@pytest.mark.parametrize("log_size", [1, 2, 5, 13, 21, 26, 30])
+def test_domain_points_match_oracle(rsv, log_size):
+    """Row a8 (reference test primitives/circle/src/lib.rs:264): bit-reversed circle-domain points."""
+    rng = np.random.default_rng(log_size)
+    q = rng.integers(0, 1 << log_size, 3000, dtype=np.uint64).astype(np.uint32)
+    q[:4] = [0, 1, (1 << log_size) - 1, (1 << log_size) >> 1]
+    got = rsv.domain_points(log_size, q)
+    assert np.array_equal(got, ob.domain_points(log_size, q))
+    x, y = got[:, 0].astype(object), got[:, 1].astype(object)
+    assert all((int(a) * int(a) + int(b) * int(b)) % P == 1 for a, b in zip(x[:64], y[:64]))
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 3, 4, 5, 8, 12])
+def test_line_eval_matches_oracle(rsv, log_n):
+    """Last layer of a12 (reference test primitives/line/src/lib.rs:82): LinePoly evaluation."""
+    rng = np.random.default_rng(100 + log_n)
+    coeffs = rng.integers(0, P, (1 << log_n, 4), dtype=np.uint32)
+    xs = rng.integers(0, P, 2000, dtype=np.uint32)
+    xs[:3] = [0, 1, P - 1]
+    assert np.array_equal(rsv.line_eval(coeffs, xs), ob.line_eval(coeffs, xs))

@@ -319,3 +319,78 @@ def test_oracle_is_clean_under_sanitizers():
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "librsv_oracle_asan.so" in out.stdout
+
+
+P31 = (1 << 31) - 1
+
+
+def _cm(a, b):  # (a0 + a1 i)(b0 + b1 i), i^2 = -1
+    return ((a[0] * b[0] - a[1] * b[1]) % P31, (a[0] * b[1] + a[1] * b[0]) % P31)
+
+
+def _qmul(x, y):  # (xa + xb u)(ya + yb u), u^2 = 2 + i   (primitives/fields/src/qm31.rs)
+    xa, xb, ya, yb = x[:2], x[2:], y[:2], y[2:]
+    bb = _cm(xb, yb)
+    r = _cm(bb, (2, 1))
+    aa = _cm(xa, ya)
+    ab, ba = _cm(xa, yb), _cm(xb, ya)
+    return ((aa[0] + r[0]) % P31, (aa[1] + r[1]) % P31, (ab[0] + ba[0]) % P31, (ab[1] + ba[1]) % P31)
+
+
+def test_field_ops_match_python_model():
+    """a1/a2: the oracle's M31 / CM31 / QM31 arithmetic against big-integer Python (products, inverses through
+    x * x^-1 = 1, powers), including the edge values 0, 1 and P - 1."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, P31, (64, 4), dtype=np.uint32)
+    b = rng.integers(0, P31, (64, 4), dtype=np.uint32)
+    a[:4] = [[0, 0, 0, 0], [1, 0, 0, 0], [P31 - 1] * 4, [0, 0, 1, 0]]
+    b[:4] = [[P31 - 1] * 4, [P31 - 1, 0, 0, 0], [P31 - 1] * 4, [0, 0, 1, 0]]
+    mul = ob.field_op(2, a, b)
+    for i in range(64):
+        assert tuple(int(v) for v in mul[i]) == _qmul([int(v) for v in a[i]], [int(v) for v in b[i]])
+    assert ob.field_op(2, [[0, 0, 1, 0]], [[0, 0, 1, 0]]).tolist() == [[2, 1, 0, 0]]  # u^2 = 2 + i
+    add, sub = ob.field_op(0, a, b), ob.field_op(1, a, b)
+    assert np.array_equal(add, ((a.astype(np.uint64) + b) % P31).astype(np.uint32))
+    assert np.array_equal(sub, ((a.astype(np.uint64) + P31 - b) % P31).astype(np.uint32))
+    inv = ob.field_op(3, a[1:])
+    assert all(tuple(int(v) for v in r) == (1, 0, 0, 0) for r in ob.field_op(2, a[1:], inv))
+    minv = ob.field_op(5, a[1:])
+    assert all(int(x[0]) * int(y[0]) % P31 == 1 for x, y in zip(a[1:], minv) if x[0])
+    cinv = ob.field_op(7, a[1:])
+    assert all(_cm((int(x[0]), int(x[1])), (int(y[0]), int(y[1]))) == (1, 0) for x, y in zip(a[1:], cinv) if x[0] or x[1])
+    assert np.array_equal(ob.field_op(8, a), ob.field_op(2, a, np.tile([0, 1, 0, 0], (64, 1))))
+    assert np.array_equal(ob.field_op(9, a), ob.field_op(2, a, np.tile([0, 0, 1, 0], (64, 1))))
+    e = np.zeros((64, 4), np.uint32)
+    e[:, 0] = rng.integers(0, 1 << 32, 64, dtype=np.uint64).astype(np.uint32)
+    e[:3, 0] = [0, 1, 5]
+    pw = ob.field_op(10, a, e)
+    for i in range(8):
+        acc, base, k = (1, 0, 0, 0), [int(v) for v in a[i]], int(e[i, 0])
+        while k:
+            if k & 1:
+                acc = _qmul(acc, base)
+            base = _qmul(base, base)
+            k >>= 1
+        assert tuple(int(v) for v in pw[i]) == tuple(acc)
+
+
+def test_line_eval_matches_fold_definition():
+    """primitives/line/src/lib.rs:39-67 restated with Python integers: fold(coeffs, [x, pi(x), ...])."""
+    rng = np.random.default_rng(4)
+    for log_n in (0, 1, 2, 4, 8):
+        coeffs = rng.integers(0, P31, (1 << log_n, 4), dtype=np.uint32)
+        xs = rng.integers(0, P31, 5, dtype=np.uint32)
+        got = ob.line_eval(coeffs, xs)
+        for t, x in enumerate(int(v) for v in xs):
+            d = []
+            for _ in range(log_n):
+                d.append(x)
+                x = (2 * x * x - 1) % P31
+
+            def fold(vals, f):
+                if len(vals) == 1:
+                    return [int(v) for v in vals[0]]
+                half = len(vals) // 2
+                lo, hi = fold(vals[:half], f[1:]), fold(vals[half:], f[1:])
+                return [(lo[k] + hi[k] * f[0]) % P31 for k in range(4)]
+            assert got[t].tolist() == fold(list(coeffs), d)
