@@ -1,0 +1,74 @@
+"""gpurun_out/<tag>/ (tools/profile.sh) -> profiles/<tag>_{bench_n1_65536.json, bench_under_rocprof.json,
+kernel_stats_bench65536.csv, pmc_summary.csv}.  Usage: python tools/pmc_summary.py r1_final"""
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_dispatch_counters(path):
+    """{kernel short name: {counter: value of the LAST dispatch}} (counter rows of one dispatch are summed over
+    their dimensions, as rocprofv3 lists one row per counter instance)."""
+    per = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = r["Kernel_Name"]
+            if "rsv::" not in name:
+                continue
+            short = name.split("(")[0].replace("void ", "")
+            d = per.setdefault(short, {})
+            key = (int(r["Dispatch_Id"]), r["Counter_Name"])
+            d[key] = d.get(key, 0.0) + float(r["Counter_Value"])
+    out = {}
+    for short, d in per.items():
+        last = max(k[0] for k in d)
+        out[short] = {c: v for (disp, c), v in d.items() if disp == last}
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r1_final"
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    shutil.copy(os.path.join(src, "bench_n1_65536.json"), os.path.join(dst, f"{tag}_bench_n1_65536.json"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.reader(open(stats)))
+    keep = [rows[0]] + [r for r in rows[1:] if "rsv::" in r[0]]
+    with open(os.path.join(dst, f"{tag}_kernel_stats_bench65536.csv"), "w", newline="") as f:
+        csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(keep)
+    avg_ms = {r[0].split("(")[0].replace("void ", ""): (int(r[1]), float(r[3]) / 1e6) for r in rows[1:] if "rsv::" in r[0]}
+    counters = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+        path = glob.glob(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)[0]
+        for k, v in last_dispatch_counters(path).items():
+            counters.setdefault(k, {}).update(v)
+    cols = ["kernel", "calls", "avg_ms", "FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_corrected", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+            "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "eff_clock_GHz", "valu_winst_per_s",
+            "valu_issue_frac_of_1.2288e12"]
+    with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
+        f.write(f"# rocprofv3 summary, {tag} build — `python bench.py --steps 1..2 --warmup 1` (65 536 proofs, 7.71 GB, one MI355X); tools/profile.sh + tools/pmc_summary.py\n")
+        f.write(f"# kernel-trace pass: profiles/{tag}_kernel_stats_bench65536.csv; counters from four separate --pmc passes (no trace domains mixed in)\n")
+        f.write("# FETCH_SIZE / WRITE_SIZE are KiB as reported; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream, MI355X_MICROARCH.md)\n")
+        f.write("# eff_clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / avg_ms; valu_issue_frac = SQ_INSTS_VALU / avg_ms against 1024 SIMDs x 2.4 GHz / 2 cycles\n")
+        f.write("# kernels on the side stream (k_row_hash, k_query, k_oods, k_qconst, k_scan) overlap main-stream kernels: their durations and clocks are not isolated\n")
+        f.write(",".join(cols) + "\n")
+        for k in sorted(avg_ms, key=lambda k: -avg_ms[k][1] * avg_ms[k][0]):
+            c = counters.get(k, {})
+            calls, ms = avg_ms[k]
+            fetch, write = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+            gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+            clock = gui / 8 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0  # GRBM_GUI_ACTIVE is reported per XCD (8), summed above
+            rate = c.get("SQ_INSTS_VALU", 0.0) / (ms * 1e-3) if ms > 0 else 0.0
+            f.write(",".join(str(x) for x in [k, calls, round(ms, 4), int(fetch), int(write), int((2 * fetch + write) * 1024),
+                                              int(c.get("SQ_INSTS_VALU", 0)), int(c.get("SQ_INSTS_SALU", 0)), int(c.get("SQ_WAVES", 0)),
+                                              int(c.get("SQ_WAVE_CYCLES", 0)), int(c.get("SQ_BUSY_CYCLES", 0)), int(gui),
+                                              round(clock, 3), f"{rate:.3e}", round(rate / 1.2288e12, 3)]) + "\n")
+    print("wrote profiles/" + tag + "_*")
+
+
+if __name__ == "__main__":
+    main()
