@@ -25,7 +25,7 @@ import numpy as np
 
 P = 0x7FFFFFFF
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librsv_hip.so")
+LIB_PATH = os.environ.get("RSV_LIB") or os.path.join(_HERE, "csrc", "librsv_hip.so")  # RSV_LIB: diagnostic builds (tools/)
 
 REASONS = ["ok", "parse", "pow", "logup", "composition", "dup_query", "merkle_t0", "merkle_t1",
            "merkle_t2", "merkle_t3", "fri_first", "fri_inner", "fri_last"]

@@ -275,8 +275,26 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     }
 }
 
+#ifdef RSV_COUNT_PERMS
+// Diagnostic build only (make count): executed permutations per kernel tag — [2t] active lanes, [2t+1] wave-level calls.
+__device__ unsigned long long g_perm_counter[16];
+__shared__ unsigned s_perm_tag;
+#define RSV_TAG(k) do { if (threadIdx.x == 0) s_perm_tag = (k); __syncthreads(); } while (0)
+#else
+#define RSV_TAG(k) do { } while (0)
+#endif
+
 // Out-of-line instance shared by every call site of the large kernels.
 __device__ __noinline__ State16 poseidon2(State16 st) {
+#ifdef RSV_COUNT_PERMS
+    {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m));
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
+        }
+    }
+#endif
     poseidon2_inline(st.s);
     return st;
 }

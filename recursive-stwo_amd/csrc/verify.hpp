@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     if (p >= n) return;
     ProofMeta& m = metas[p];
     ctxs[p].flags = 0;
-    shape[p] = 0;
+    shape[2 * p] = 0;
+    shape[2 * p + 1] = 0;
     uint64_t o0 = offsets[p], o1 = offsets[p + 1];
     m.reason = R_PARSE;
     m.nq = 0; m.M = 0; m.n_inner = 0;
@@ -150,9 +151,15 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     atomicMax(&summary[3], 64u - (last + b + 1u));  // 64 - (lowest data / leaf level of any tree)
     // shape word for host-side bucketing + "is the batch uniform" summary (max of x and of ~x)
     const uint32_t sw = nq | (M << 8) | (n_inner << 16) | ((last + b + 1u) << 24);
-    shape[p] = sw;
+    // second word: the column log sizes (two proofs with equal first words can still differ in A / B, and lanes of
+    // one wavefront should walk trees of ONE geometry: the host orders the slots of a bucket by both words)
+    const uint32_t sw2 = A | (B << 8);
+    shape[2 * p] = sw;
+    shape[2 * p + 1] = sw2;
     atomicMax(&summary[4], sw);
     atomicMax(&summary[5], ~sw);
+    atomicMax(&summary[6], sw2);
+    atomicMax(&summary[7], ~sw2);
 }
 
 // ------------------------------------------------------------------- k_scan
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, 
 __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                    uint32_t n, const ProofMeta* __restrict__ metas,
                                                    ProofCtx* __restrict__ ctxs) {
+    RSV_TAG(1);
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const ProofMeta& m = metas[p];
@@ -1064,6 +1072,7 @@ struct RowHashArgs {
 };
 
 __global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
+    RSV_TAG(2);
     const uint32_t G = a.G, per_block = 256 / G;
     const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
     const uint32_t slot = blockIdx.x * per_block + grp;
@@ -1187,6 +1196,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
+    RSV_TAG(3);
     __shared__ uint32_t xch[2][BLOCK][8];
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
@@ -1294,6 +1304,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
 // column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
+    RSV_TAG(4);
     __shared__ uint32_t xch[2][BLOCK][8];
     __shared__ uint32_t xch2[BLOCK][8];  // path emission only: pre-column node hashes at data levels
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)

@@ -1,0 +1,46 @@
+"""How many Poseidon2 permutations does each kernel execute per proof, against the oracle's count of the batched
+minimum?  Needs the diagnostic build: make -C recursive-stwo_amd/csrc count.  Usage: python tools/perm_census.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["RSV_LIB"] = os.path.join(ROOT, "recursive-stwo_amd", "csrc", "librsv_hip_count.so")
+import rsvload  # noqa: E402
+from tests import oracle_binding as ob  # noqa: E402
+
+rsv = rsvload.load_package()
+
+
+TAGS = {0: "other", 1: "k_transcript", 2: "k_row_hash", 3: "k_trace_merkle", 4: "k_pair_merkle"}
+
+
+def counter():
+    out = (ctypes.c_ulonglong * 16)()
+    assert rsv.lib.rsv_debug_perm_counter(out) == 0
+    return [(int(out[2 * t]), int(out[2 * t + 1])) for t in range(8)]
+
+
+def main():
+    n = 4096
+    for name in ("recursive_proof_16_15.bin", "level3-1.bin", "level1-5.bin", "level12-1.bin"):
+        proof = open(os.path.join(ROOT, "tests", "golden", "proofs", name), "rb").read()
+        want = ob.perm_count(proof)
+        counter()
+        for env in ("1", "0"):
+            os.environ["RSV_CAP"] = env
+            os.environ["RSV_TRANSCRIPT"] = "lane"
+            acc, _ = rsv.verify_batch([proof] * n)
+            assert acc.all()
+            per = counter()
+            lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)
+            print("   " + ", ".join(f"{TAGS[t]} {per[t][0] / n:.1f} lanes / {per[t][1] * 64 / n:.1f} slots" for t in TAGS if per[t][1]))
+            print(f"{name}: oracle (batched walk) {want} perms/proof; GPU cap={env}: {lanes / n:.1f} lane-perms/proof "
+                  f"({lanes / n / want:.3f}x), {waves * 64 / n:.1f} wave-slot perms/proof ({waves * 64 / n / want:.3f}x)")
+
+
+if __name__ == "__main__":
+    main()
