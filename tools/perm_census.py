@@ -42,5 +42,26 @@ def main():
                   f"({lanes / n / want:.3f}x), {waves * 64 / n:.1f} wave-slot perms/proof ({waves * 64 / n / want:.3f}x)")
 
 
+def mixed():
+    """the bench workloads: round-robin mixes, where one wavefront used to see several tree geometries"""
+    mixes = {"standard": ["recursive_proof_16_15.bin", "level3-1.bin", "level6-1.bin", "level7-1.bin"],
+             "chain": ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+                       "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]}
+    os.environ["RSV_CAP"] = "1"
+    for label, names in mixes.items():
+        proofs = [open(os.path.join(ROOT, "tests", "golden", "proofs", f), "rb").read() for f in names]
+        want = sum(ob.perm_count(p) for p in proofs) / len(proofs)
+        n = 4160 if label == "chain" else 4096
+        counter()
+        acc, _ = rsv.verify_batch([proofs[i % len(proofs)] for i in range(n)])
+        assert acc.all()
+        per = counter()
+        lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)
+        print("   " + ", ".join(f"{TAGS[t]} {per[t][0] / n:.1f} lanes / {per[t][1] * 64 / n:.1f} slots" for t in TAGS if per[t][1]))
+        print(f"{label} mix: oracle {want:.0f} perms/proof; GPU {lanes / n:.1f} lane-perms ({lanes / n / want:.3f}x), "
+              f"{waves * 64 / n:.1f} wave-slot perms ({waves * 64 / n / want:.3f}x)")
+
+
 if __name__ == "__main__":
+    mixed()
     main()
