@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
