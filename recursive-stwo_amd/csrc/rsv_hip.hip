@@ -44,7 +44,7 @@ struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
@@ -104,6 +104,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
         hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ids, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess) {
         rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
@@ -122,6 +123,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_tr) (void)hipEventDestroy(c->ev_tr);
+    if (c->ev_ids) (void)hipEventDestroy(c->ev_ids);
     if (c->ev_query) (void)hipEventDestroy(c->ev_query);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
