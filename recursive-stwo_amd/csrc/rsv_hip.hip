@@ -17,6 +17,7 @@
 #include <new>
 #include <system_error>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "primitives.hpp"
