@@ -1,0 +1,43 @@
+// examples/single_proof.cpp — the verify half of the reference's examples/single-proof/src/main.rs:23-82 on the
+// MI355X library: read one serialized proof, derive the hints (one verifying pass on the GPU), check the per-query
+// paths the way the reference's hint constructors do, and run the four verifier stages.
+//
+//   g++ -std=c++17 -O1 -o single_proof examples/single_proof.cpp -Lrecursive-stwo_amd/csrc -lrsv_hip \
+//       -Wl,-rpath,$PWD/recursive-stwo_amd/csrc -Wl,-rpath,/opt/rocm/lib
+//   ./single_proof tests/golden/proofs/small_proof.bin
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <string>
+
+#include "../recursive-stwo_amd/host/recursive_stwo.hpp"
+
+using namespace recursive_stwo;
+
+int main(int argc, char** argv) {
+    const std::string path = argc > 1 ? argv[1] : "tests/golden/proofs/small_proof.bin";
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 2; }
+    std::vector<uint8_t> proof((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+
+    // examples/single-proof/src/main.rs:28-31,33
+    const PcsConfig config{20, FriConfig::make(2, 5, 16)};
+    const Inputs inputs = {{1, QM31{1, 0, 0, 0}}};
+    try {
+        // FiatShamirHints / DecommitHints / FirstLayerHints / InnerLayersHints (:33-41)
+        Hints hints = Hints::compute(proof, inputs);
+        size_t paths = 0;
+        for (auto& tree : hints.decommit) for (auto& p : tree) { p.verify(); paths++; }
+        for (auto& p : hints.first_layer_merkle_proofs) { p.verify(); paths++; }
+        for (auto& layer : hints.inner_layers_merkle_proofs) for (auto& p : layer.second) { p.verify(); paths++; }
+        printf("hints: %zu queries, %zu FRI inner layers, %zu per-query Merkle paths re-verified\n",
+               hints.fiat_shamir.raw_queries.size(), hints.inner_layers_merkle_proofs.size(), paths);
+        // FiatShamirResults -> CompositionCheck -> AnswerResults -> FoldingResults (:48-82)
+        Verifier::verify(proof, config, inputs);
+        printf("proof accepted\n");
+    } catch (const VerificationError& e) {
+        printf("proof rejected: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -26,3 +26,29 @@ def test_host_mirror_runs_reference_tests(tmp_path):
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "proofs")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def _build_example(tmp_path, name):
+    exe = os.path.join(str(tmp_path), name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "examples", name + ".cpp"),
+                           "-L" + CSRC, "-lrsv_hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_examples_compile(tmp_path):
+    _build_example(tmp_path, "single_proof")
+    _build_example(tmp_path, "multi_proofs")
+
+
+@pytest.mark.gpu
+def test_examples_run(tmp_path):
+    """The C++ counterparts of the reference's examples/single-proof and examples/multi-proofs."""
+    proofs = os.path.join(ROOT, "tests", "golden", "proofs")
+    out = subprocess.run([_build_example(tmp_path, "single_proof"), os.path.join(proofs, "small_proof.bin")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "proof accepted" in out.stdout and "192 per-query Merkle paths" in out.stdout, out.stdout + out.stderr
+    files = [os.path.join(proofs, f) for f in ("level1-5.bin", "level7-1.bin", "level13-1.bin", "hybrid_hash.bin")]
+    out = subprocess.run([_build_example(tmp_path, "multi_proofs")] + files, capture_output=True, text=True)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 1 and len(lines) == 4, out.stdout + out.stderr
+    assert all("accepted" in l for l in lines[:3]) and "REJECTED (stage 1)" in lines[3]
