@@ -690,6 +690,192 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
 #undef SQ
 }
 
+// ------------------------------------------------------------------ k_plan_par
+// The same tables as k_plan, computed with one lane per (proof, query) like the other per-query kernels instead of
+// one lane per proof (whose serial walk over LDS costs ~0.2 ms of pure latency per launch).  Everything follows
+// from ONE family of bitmasks per proof: F[l] has bit j set when sorted query j is the first lane of a distinct
+// node at tree level l (node = q >> (M - l)).  With N_l(x) = popcount(F[l] & bits[0..x]):
+//   distinct nodes left of lane j at level l              N_l(j) - 1
+//   a parent (level l-1 node, lanes s..e) has both children   N_l(e) - N_l(s) == 1; the right child starts at the
+//                                                          one bit of F[l] & ~F[l-1] inside (s, e]
+//   parents left of s that lack a child                    2 * popc(F[l-1] & below(s)) - popc(F[l] & below(s))
+// The first-layer pair tree adds per-level witness weights (see k_plan); their prefix sums over the nodes of a level
+// are popcounts of the same masks, and the running total over levels is a 30-step scan done by one lane.
+struct M128 {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ M128 m128_below(uint32_t x) {  // bits [0, x), x <= 128
+    M128 r;
+    r.lo = x >= 64 ? ~0ull : ((1ull << x) - 1ull);
+    r.hi = x <= 64 ? 0ull : (x >= 128 ? ~0ull : ((1ull << (x - 64)) - 1ull));
+    return r;
+}
+__device__ __forceinline__ M128 m128_and(M128 a, M128 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ M128 m128_andn(M128 a, M128 b) { return {a.lo & ~b.lo, a.hi & ~b.hi}; }
+__device__ __forceinline__ uint32_t m128_pop(M128 a) { return (uint32_t)(__popcll(a.lo) + __popcll(a.hi)); }
+__device__ __forceinline__ uint32_t m128_popbelow(M128 a, uint32_t x) { return m128_pop(m128_and(a, m128_below(x))); }
+// highest set bit at or below x (the mask has bit 0 set), lowest set bit above x or `none`
+__device__ __forceinline__ uint32_t m128_last_le(M128 a, uint32_t x) {
+    M128 t = m128_and(a, m128_below(x + 1));
+    return t.hi ? 127u - (uint32_t)__clzll((long long)t.hi) : 63u - (uint32_t)__clzll((long long)t.lo);
+}
+__device__ __forceinline__ uint32_t m128_first_gt(M128 a, uint32_t x, uint32_t none) {
+    M128 t = m128_andn(a, m128_below(x + 1));
+    if (t.lo) return (uint32_t)__ffsll((long long)t.lo) - 1u;
+    if (t.hi) return 63u + (uint32_t)__ffsll((long long)t.hi);
+    return none;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                    uint32_t n, const ProofMeta* __restrict__ metas,
+                                                    ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+    __shared__ unsigned long long F[64][32][2];   // per_block <= 64 proofs, levels 0..30
+    __shared__ uint32_t raw[BLOCK], sq[BLOCK];
+    __shared__ uint8_t sp[BLOCK];
+    __shared__ uint32_t tl[64][32];               // per level: nodes | lacking << 8
+    __shared__ uint32_t tw[64][32];               // per node level: witness weight of the first-layer pair tree
+    __shared__ uint32_t wsum[64][32];             // wf[l + 1]
+    const uint32_t G = pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * per_block + grp;
+    bool livep = grp < per_block && slot < n;
+    const uint32_t p = livep ? pl.proof_of(slot) : 0u;
+    const ProofMeta* m = livep ? &metas[p] : nullptr;
+    livep = livep && m->reason == R_OK;
+    const uint32_t nq = livep ? m->nq : 0u, M = livep ? m->M : 1u, A = livep ? m->A : 0u, B = livep ? m->B : 0u;
+    const bool live = livep && j < nq;
+    ProofCtx* c = livep ? &ctxs[p] : nullptr;
+    const uint32_t gbase = grp * G;
+    for (uint32_t i = threadIdx.x; i < 64u * 32u * 2u; i += BLOCK) (&F[0][0][0])[i] = 0ull;
+    const uint32_t v0 = live ? (c->raw_q[j] & ((1u << M) - 1u)) : 0xFFFFFFFFu;
+    raw[threadIdx.x] = v0;
+    __syncthreads();
+    // rank sort (primitives/query/src/lib.rs:19-38): ties broken by transcript index, as the insertion sort does
+    if (live) {
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < nq; k++) {
+            const uint32_t vk = raw[gbase + k];
+            rank += (vk < v0 || (vk == v0 && k < j)) ? 1u : 0u;
+        }
+        sq[gbase + rank] = v0;
+        sp[gbase + rank] = (uint8_t)j;
+    }
+    __syncthreads();
+    uint32_t flags = 0;
+    const uint32_t v = live ? sq[gbase + j] : 0u;
+    if (live) {
+        c->q[j] = v;
+        c->qperm[j] = sp[gbase + j];
+        if (j + 1 < nq && sq[gbase + j + 1] == v) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
+        // lane j starts a new node at every level l >= M - (highest bit in which it differs from lane j-1)
+        uint32_t lstart = 0;
+        if (j > 0) {
+            const uint32_t x = v ^ sq[gbase + j - 1];
+            lstart = x ? M - (31u - (uint32_t)__clz((int)x)) : M + 1u;
+        }
+        for (uint32_t l = lstart; l <= M; l++) atomicOr(&F[grp][l][j >> 6], 1ull << (j & 63u));
+    }
+    __syncthreads();
+    auto mask = [&](uint32_t l) { return M128{F[grp][l][0], F[grp][l][1]}; };
+    // column log sizes, descending
+    uint32_t sizes[3] = {M, A == B ? A : umax(A, B), A == B ? 0u : umin(A, B)};
+    const uint32_t n_sizes = A == B ? 2u : 3u;
+    auto is_size = [&](uint32_t l) { return l == sizes[0] || l == sizes[1] || (n_sizes == 3 && l == sizes[2]); };
+    // per-level totals, levels dealt round-robin to the proof's lanes
+    if (live) {
+        for (uint32_t l = j; l <= M; l += nq) {
+            const M128 Fl = mask(l);
+            const uint32_t nodes = m128_pop(Fl);
+            uint32_t lacking = 0;
+            if (l >= 1) lacking = 2u * m128_pop(mask(l - 1)) - nodes;
+            tl[grp][l] = nodes | (lacking << 8);
+            if (l < M) {
+                const uint32_t both_total = m128_pop(m128_andn(mask(l + 1), Fl));
+                const uint32_t nosib_total = l == 0 ? 1u : m128_pop(mask(l - 1)) - m128_pop(m128_andn(Fl, mask(l - 1)));
+                tw[grp][l] = (is_size(l + 1) ? 0u : nodes - both_total) + (is_size(l) ? 2u * nosib_total : 0u);
+            }
+        }
+    }
+    __syncthreads();
+    PlanHdr* h = livep ? &pl.hdr[slot] : nullptr;
+    if (live && j == 0) {
+        uint32_t suffix = 0;
+        h->lvl[M + 1] = 0;
+        for (uint32_t l = M; l >= 1; l--) {
+            suffix += (tl[grp][l] >> 8) & 0xFFu;
+            h->lvl[l] = tl[grp][l] | (suffix << 16);
+        }
+        h->lvl[0] = 1u | (suffix << 16);
+        uint32_t W = 0;
+        for (uint32_t l = M; l-- > 0;) {
+            wsum[grp][l] = W;
+            h->wf[l + 1] = (uint16_t)W;
+            W += tw[grp][l];
+        }
+        h->wf[0] = (uint16_t)W;
+        h->wf_total = (uint16_t)umin(W, 0xFFFFu);
+        c->n_sizes = n_sizes;
+        c->sizes[0] = sizes[0]; c->sizes[1] = sizes[1]; c->sizes[2] = n_sizes == 3 ? sizes[2] : 0u;
+        // first-layer fri_witness bases (components/hints/src/folding.rs:414-451)
+        uint32_t base = 0;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            c->fw_base[g] = base;
+            base += (tl[grp][sizes[g]] >> 8) & 0xFFu;
+        }
+        if (base != m->first.wit_n) flags |= 1u << R_FRI_FIRST;
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t* ent = pl.ent + (size_t)slot * (pl.maxM + 1) * G;
+        uint32_t* fl = pl.fl + (size_t)slot * 2 * G;
+        ent[j] = 0xFFu << 16;
+        for (uint32_t l = 1; l <= M; l++) {
+            const M128 Fl = mask(l), Fp = mask(l - 1);
+            const uint32_t s = m128_last_le(Fp, j);                     // first lane of my parent's run
+            const uint32_t e = m128_first_gt(Fp, j, nq) - 1u;           // its last lane
+            const uint32_t Ns = m128_popbelow(Fl, s + 1), Ne = m128_popbelow(Fl, e + 1), Nj = m128_popbelow(Fl, j + 1);
+            const bool both = Ne - Ns == 1u;
+            const bool right = both && Nj - Ns == 1u;
+            const uint32_t second = both ? m128_first_gt(Fl, s, nq) : 0u;  // first lane of the right child
+            const uint32_t sib = both ? (right ? second - 1u : second) : 0xFFu;
+            const uint32_t lack_before = 2u * m128_popbelow(Fp, s) - m128_popbelow(Fl, s);
+            ent[l * G + j] = (Nj - 1u) | (lack_before << 8) | (sib << 16);
+        }
+        // first-layer pair tree: witness indices at the (up to two) non-leaf column levels (folding.rs:107-206)
+        for (uint32_t d = 0; d + 1 < n_sizes; d++) {
+            const uint32_t l = sizes[1 + d];
+            if (l >= M) continue;
+            const M128 Fl = mask(l), Fc = mask(l + 1);
+            const uint32_t f = m128_last_le(Fl, j), e = m128_first_gt(Fl, j, nq) - 1u;
+            const bool has_both = m128_popbelow(Fc, e + 1) - m128_popbelow(Fc, f + 1) == 1u;
+            const bool child_data = is_size(l + 1);
+            const bool lack = !child_data && !has_both;
+            bool sib_present = false;
+            uint32_t nosib_before = 0;
+            if (l >= 1) {
+                const M128 Fp = mask(l - 1);
+                const uint32_t s = m128_last_le(Fp, j), pe = m128_first_gt(Fp, j, nq) - 1u;
+                sib_present = m128_popbelow(Fl, pe + 1) - m128_popbelow(Fl, s + 1) == 1u;
+                nosib_before = m128_popbelow(Fp, s) - m128_popbelow(m128_andn(Fl, Fp), s);
+            }
+            const uint32_t nodes_before = m128_popbelow(Fl, f), both_before = m128_popbelow(m128_andn(Fc, Fl), f);
+            const uint32_t base = wsum[grp][l] + (child_data ? 0u : nodes_before - both_before) + 2u * nosib_before;
+            const bool odd = (v >> (M - l)) & 1u;
+            uint32_t w_self = 0xFFFFu, w_sib = 0xFFFFu;
+            if (odd) {
+                if (!sib_present) w_sib = base;
+                if (lack) w_self = base + (sib_present ? 0u : 2u);
+            } else {
+                if (lack) w_self = base;
+                if (!sib_present) w_sib = base + (lack ? 1u : 0u);
+            }
+            fl[d * G + j] = (w_self & 0xFFFFu) | (w_sib << 16);
+        }
+    }
+    if (flags) atomicOr(&c->flags, flags);
+}
+
 // ------------------------------------------------------------------ k_export_transcript
 // One lane per output word: ProofCtx -> the flat row layout of include/rsv.h (RSV_TRANSCRIPT_WORDS).
 constexpr uint32_t TR_WORDS = 40 + 4 * (MAX_INNER + 1) + MAXQ;

@@ -544,3 +544,18 @@ def test_line_eval_matches_oracle(rsv, log_n):
     xs = rng.integers(0, P, 2000, dtype=np.uint32)
     xs[:3] = [0, 1, P - 1]
     assert np.array_equal(rsv.line_eval(coeffs, xs), ob.line_eval(coeffs, xs))
+
+
+def test_plan_kernels_serial_and_parallel(rsv, manifest, monkeypatch):
+    """The decommitment plan has two implementations — one lane per (proof, query) with bitmask popcounts (default)
+    and the one-lane-per-proof walk it replaced (RSV_PLAN=serial).  Both must give the oracle's verdicts on the
+    whole fixture set plus structural mutants (whose rejection reasons depend on the plan's witness counts)."""
+    proofs = [read_proof(e["file"]) for e in manifest if entry_inputs(e) == list(rsv.STANDARD_INPUTS)]
+    batch = list(proofs)
+    for pr in proofs[:4]:
+        batch += [b for _, b in ob.structural_mutants(pr)]
+    oacc, oreason = ob.verify_batch(batch)
+    for mode in ("serial", "parallel"):
+        monkeypatch.setenv("RSV_PLAN", mode)
+        acc, reason = rsv.verify_batch(batch)
+        assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), mode
