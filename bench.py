@@ -77,7 +77,7 @@ def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
     return d_blob, d_offsets, plen, np.array(tam, dtype=np.int64)
 
 
-def cpu_baseline(blob_host, offsets, n_sample):
+def cpu_baseline(blob_host, offsets, n_sample, fixtures=None):
     """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores."""
     from tests import oracle_binding as ob
     threads = max(1, min(os.cpu_count() or 1, 16))
@@ -100,8 +100,12 @@ def cpu_baseline(blob_host, offsets, n_sample):
     with ThreadPoolExecutor(threads) as ex:
         accepted = sum(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
+    # Poseidon2 permutations the oracle's batched walk spends on the genuine fixtures of this workload (untimed): the
+    # unit of useful work of this path, used for the in-situ permutation rate reported next to the microbenchmark
+    perms = [ob.perm_count(read_fixture(f)) for f in fixtures] if fixtures else []
     return {"value": n_sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads"}
+            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads",
+            "perms_per_proof": (sum(perms) / len(perms)) if perms else None}
 
 
 def main():
@@ -291,7 +295,12 @@ def main():
         n_s = min(sample, n)
         end = int(d_offsets[n_s].item())
         blob_host = d_blob[:end].cpu().numpy()
-        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s)
+        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s, fixtures)
+        if valu is not None and cpu.get("perms_per_proof"):
+            # useful permutations (the oracle's batched-walk count) the pipeline retires per second, against the bare
+            # permutation kernel measured above: the efficiency figure of this VALU-bound path
+            valu["pipeline_useful_perms_per_s"] = cpu["perms_per_proof"] * value
+            valu["pipeline_frac_of_perm_kernel"] = valu["pipeline_useful_perms_per_s"] / (world * valu["poseidon2_perms_per_s"])
 
     line = {
         "metric": "recursive proofs verified/sec", "value": value, "unit": "proofs/s", "n_gpus": world,

@@ -50,6 +50,8 @@ def test_bench_single_gpu_line():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check_line(out.stdout, 1)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert 4000 < d["cpu_baseline"]["perms_per_proof"] < 6000
+    assert 0 < d["valu"]["pipeline_frac_of_perm_kernel"] < 1.5
 
 
 @pytest.mark.gpu
