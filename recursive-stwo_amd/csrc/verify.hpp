@@ -1326,10 +1326,12 @@ struct CapGroup {
     uint32_t hw_n, s_top, active, fail_bit;
 };
 
+// emit (optional, path emission): this lane's path buffer; the sibling consumed at child level l + 1 goes to entry
+// emit_top - l (8 words each), so a query's path is complete although its lane does not walk the top levels.
 template <int BLOCK>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
-                                           const Hash8& cur) {
+                                           const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0) {
     const uint32_t t = threadIdx.x;
     __syncthreads();  // xch is free, descriptors written
     if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
@@ -1341,6 +1343,22 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
     __syncthreads();
     uint32_t bufi = 0;
     for (uint32_t l = Lc; l-- > 0;) {  // parent level
+        if (emit && live) {
+            // the query's ancestor at child level l + 1 and its sibling: a present node (LDS) or the witness entry
+            // its parent consumes (same rank as below)
+            const CapGroup& d = grp_desc[grp];
+            const uint32_t anc = pos >> (Lc - 1u - l), par = anc >> 1;
+            const unsigned long long cm = mask[bufi][grp];
+            Hash8 sib = zero8();
+            if (((cm >> (2 * par)) & 3u) == 3u) sib = load_hash(&xch[bufi][(grp << (l + 1)) + (anc ^ 1u)][0]);
+            else {
+                const unsigned long long lack = (cm ^ (cm >> 1)) & 0x5555555555555555ull;
+                const uint32_t rank = __popcll(lack & ((1ull << (2 * par)) - 1ull));
+                const uint32_t base = d.wf ? (uint32_t)d.wf[l + 1] : lvl_s(d.lvl[l + 2]) - d.s_top;
+                if (base + rank < d.hw_n) sib = load_hash(d.hw + 8 * (base + rank));
+            }
+            store_hash(emit + (size_t)(emit_top - l) * 8, sib);
+        }
         const uint32_t g2 = t >> l, ppos = t & ((1u << l) - 1u);
         if (g2 < per_block && grp_desc[g2].active) {
             const CapGroup& d = grp_desc[g2];
@@ -1481,7 +1499,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         bool ok = !bad && want_qv == qv_n && want_hw == hw_n && (Lc || hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t)));
         if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (R_MERKLE_T0 + t));
     }
-    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur);
+    if (Lc) {
+        uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
+        merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u);
+    }
 }
 
 // ------------------------------------------------------------ k_pair_merkle
@@ -1608,7 +1629,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
         bool ok = !bad && want_hw == L->hash_n && (Lc || hash_eq(cur, load_hash(w + L->commit_off)));
         if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER));
     }
-    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur);
+    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u);
 }
 
 // --------------------------------------------------------------- k_finalize
