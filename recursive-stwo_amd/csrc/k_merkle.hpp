@@ -1,0 +1,401 @@
+// k_merkle.hpp — column hashing (k_row_hash), trace trees (k_trace_merkle), top-of-tree cap, FRI pair trees (k_pair_merkle).  Part of the pipeline described in verify.hpp.
+#pragma once
+#include "k_query.hpp"
+
+namespace rsv {
+
+// --------------------------------------------------------------- k_row_hash
+// Column hashing of the trace trees does not depend on the transcript: queried_values lists one row of
+// column values per distinct queried node, in ascending node order, leaf level first.  The sponge over row r
+// (primitives/merkle/src/lib.rs:50-181) can therefore run UNDERNEATH the latency-bound transcript kernel
+// (side stream): one lane per (proof, tree, row) hashes leaf-level row r counted from the start of
+// queried_values and lower-level row r counted from its END (where that block begins depends on how many
+// leaves are distinct, which is only known once the queries are).  k_trace_merkle then just picks its rows.
+//   rowh[((p*4 + t)*2 + 0)*G + r] = leaf hash of leaf row r
+//   rowh[((p*4 + t)*2 + 1)*G + r] = column capacity digest of the r-th LAST lower-level row
+struct RowHashArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n, G;         // slots in this launch, lanes per proof (= n_queries of the bucket)
+    const ProofMeta* metas;
+    uint32_t* rowh;        // [proof][4][2][Grow][8]
+    uint32_t Grow;         // row stride of rowh (max n_queries of the batch)
+    const uint32_t* ids;   // slot -> proof (nullptr: identity)
+};
+
+__global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
+    RSV_TAG(2);
+    const uint32_t G = a.G, per_block = 256 / G;
+    const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * per_block + grp;
+    const int t = blockIdx.y;
+    if (grp >= per_block || slot >= a.n) return;
+    const uint32_t p = a.ids ? a.ids[slot] : slot;
+    const ProofMeta& m = a.metas[p];
+    if (m.reason != R_OK || r >= m.nq) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+    const uint32_t A = m.A, B = m.B, M = m.M;
+    const uint32_t mx = (t == 3) ? M : umax(A, B);
+    const uint32_t nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+    const uint32_t nc_lower = (t == 3 || A == B) ? 0u : (A < B ? plonk_cols(t) : poseidon_cols(t));
+    const uint32_t* qv = w + m.qv_off[t];
+    const uint32_t qv_n = m.qv_n[t];
+    uint32_t* out = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
+    if ((r + 1) * nc_leaf <= qv_n) store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity(qv + r * nc_leaf, nc_leaf)));
+    if (nc_lower && (r + 1) * nc_lower <= qv_n)
+        store_hash(out + ((size_t)a.Grow + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
+}
+
+// ----------------------------------------------------------- k_trace_merkle
+// SinglePathMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:315-354)
+// for the four commitment trees: blockIdx.y = tree, one lane per (proof, query).
+struct MerkleArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n;
+    const ProofMeta* metas;
+    ProofCtx* ctxs;
+    PlanPtrs pl;
+    const uint32_t* leafv;
+    uint32_t maxInner;
+    uint32_t Lc;  // cap level: levels below Lc are hashed by merkle_cap (0 = walk every path to the root)
+    const uint32_t* rowh;  // k_row_hash output, [proof][4][2][Grow][8]
+    uint32_t Grow;
+    // optional per-query authentication paths of the trace trees, transcript query order:
+    //   path_sib[((slot*4 + t)*G + i)*maxM + k]  = sibling hash at the k-th level above the leaf (8 words)
+    //   path_pos[(slot*4 + t)*G + i]              = position of query i at the tree's leaf level
+    uint32_t* path_sib;
+    uint32_t* path_pos;
+    //   path_cols[((slot*4 + t)*G + i)*64 + k]    = SinglePathMerkleProof::columns: the leaf-level column values of
+    //                                               query i, then those at the lower column log size (may be null)
+    uint32_t* path_cols;
+    // optional per-query pair paths of the FRI trees (SinglePairMerkleProof, components/hints/src/folding.rs:214-287):
+    //   pair_sib [(((slot*(1+maxInner) + s)*G + i)*maxM + k]  sibling_hashes[k] of tree s (0 = first layer), 8 words
+    //   pair_cols[(((slot*(1+maxInner) + s)*G + i)*3 + c]     c-th data level from the top: self | sibling value, 8 words
+    uint32_t* pair_sib;
+    uint32_t* pair_cols;
+};
+
+// ---------------------------------------------------------------- merkle_cap
+// Top of a tree.  Below level Lc (2^Lc <= queries per proof) the query paths of a proof have merged into
+// at most 2^l distinct nodes per level, so continuing one-lane-per-path would hash every shared node up to
+// n_queries times.  Here the lanes of the workgroup are re-dealt densely over (proof, node position): level
+// l costs per_block * 2^l lanes instead of per_block * G.  Nodes live in LDS (xch, two buffers), presence
+// in a per-proof bitmask; a missing child is the next hash_witness entry in ascending node order, exactly
+// the batched order of components/hints/src/decommit.rs:91-139 and folding.rs:116-206.
+struct CapGroup {
+    const uint32_t* hw;    // hash witness of this (proof, tree)
+    const uint32_t* lvl;   // PlanHdr::lvl
+    const uint16_t* wf;    // PlanHdr::wf (first-layer pair tree) or nullptr
+    const uint32_t* root;  // expected root (8 words)
+    uint32_t* flags;       // ProofCtx::flags
+    uint32_t hw_n, s_top, active, fail_bit;
+};
+
+// emit (optional, path emission): this lane's path buffer; the sibling consumed at child level l + 1 goes to entry
+// emit_top - l (8 words each), so a query's path is complete although its lane does not walk the top levels.
+template <int BLOCK>
+__device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
+                                           uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
+                                           const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0) {
+    const uint32_t t = threadIdx.x;
+    __syncthreads();  // xch is free, descriptors written
+    if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
+    __syncthreads();
+    if (live) {
+        store_hash(xch[0][(grp << Lc) + pos], cur);
+        atomicOr(&mask[0][grp], 1ull << pos);
+    }
+    __syncthreads();
+    uint32_t bufi = 0;
+    for (uint32_t l = Lc; l-- > 0;) {  // parent level
+        if (emit && live) {
+            // the query's ancestor at child level l + 1 and its sibling: a present node (LDS) or the witness entry
+            // its parent consumes (same rank as below)
+            const CapGroup& d = grp_desc[grp];
+            const uint32_t anc = pos >> (Lc - 1u - l), par = anc >> 1;
+            const unsigned long long cm = mask[bufi][grp];
+            Hash8 sib = zero8();
+            if (((cm >> (2 * par)) & 3u) == 3u) sib = load_hash(&xch[bufi][(grp << (l + 1)) + (anc ^ 1u)][0]);
+            else {
+                const unsigned long long lack = (cm ^ (cm >> 1)) & 0x5555555555555555ull;
+                const uint32_t rank = __popcll(lack & ((1ull << (2 * par)) - 1ull));
+                const uint32_t base = d.wf ? (uint32_t)d.wf[l + 1] : lvl_s(d.lvl[l + 2]) - d.s_top;
+                if (base + rank < d.hw_n) sib = load_hash(d.hw + 8 * (base + rank));
+            }
+            store_hash(emit + (size_t)(emit_top - l) * 8, sib);
+        }
+        const uint32_t g2 = t >> l, ppos = t & ((1u << l) - 1u);
+        if (g2 < per_block && grp_desc[g2].active) {
+            const CapGroup& d = grp_desc[g2];
+            const unsigned long long cm = mask[bufi][g2];
+            const uint32_t pres = (uint32_t)(cm >> (2 * ppos)) & 3u;
+            if (pres) {
+                const unsigned long long even = 0x5555555555555555ull;
+                const unsigned long long lack = (cm ^ (cm >> 1)) & even;  // bit 2p': exactly one child present
+                const uint32_t rank = __popcll(lack & ((1ull << (2 * ppos)) - 1ull));
+                const uint32_t base = d.wf ? (uint32_t)d.wf[l + 1] : lvl_s(d.lvl[l + 2]) - d.s_top;
+                const uint32_t* kids = &xch[bufi][(g2 << (l + 1)) + 2 * ppos][0];
+                Hash8 left, right;
+                bool bad = false;
+                if (pres == 3u) { left = load_hash(kids); right = load_hash(kids + 8); }
+                else {
+                    const uint32_t wi = base + rank;
+                    Hash8 w8 = zero8();
+                    if (wi < d.hw_n) w8 = load_hash(d.hw + 8 * wi);
+                    else bad = true;
+                    left = (pres & 1u) ? load_hash(kids) : w8;
+                    right = (pres & 2u) ? load_hash(kids + 8) : w8;
+                }
+                Hash8 node = hash_tree(left, right);
+                if (l == 0) {
+                    if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, 1u << d.fail_bit);
+                } else {
+                    if (bad) atomicOr(d.flags, 1u << d.fail_bit);
+                    store_hash(xch[bufi ^ 1][(g2 << l) + ppos], node);
+                    atomicOr(&mask[bufi ^ 1][g2], 1ull << ppos);
+                }
+            }
+        }
+        __syncthreads();
+        if (t < per_block) mask[bufi][t] = 0;
+        bufi ^= 1;
+        __syncthreads();
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
+    RSV_TAG(3);
+    __shared__ uint32_t xch[2][BLOCK][8];
+    __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
+    __shared__ CapGroup capgrp[64];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t slot_ = blockIdx.x * per_block + grp;
+    const int t = blockIdx.y;
+    bool live = grp < per_block && slot_ < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq;
+    const uint32_t gbase = grp * G;
+    const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
+    uint32_t M = 0, A = 0, B = 0, mx = 0, nc_leaf = 0, qv_n = 0, hw_n = 0, s_top = 0, nd_leaf = 0;
+    const uint32_t *hw = nullptr, *rows = nullptr;
+    bool bad = false;
+    Hash8 cur = zero8();
+    uint32_t qj = 0;
+    if (live) {
+        w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+        ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
+        h = &a.pl.hdr[slot_];
+        M = m->M; A = m->A; B = m->B;
+        mx = (t == 3) ? M : umax(A, B);
+        nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+        qv_n = m->qv_n[t];
+        hw = w + m->hw_off[t]; hw_n = m->hw_n[t];
+        s_top = lvl_s(h->lvl[mx + 1]);
+        nd_leaf = lvl_nd(h->lvl[mx]);
+        qj = a.ctxs[p].q[j];
+        rows = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
+        const uint32_t row = ent_rb(ent[mx * G + j]);
+        if ((row + 1) * nc_leaf > qv_n) bad = true;
+        else {
+            cur = load_hash(rows + (size_t)row * 8);
+            if (a.path_cols) {
+                uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64;
+                const uint32_t* src = w + m->qv_off[t] + row * nc_leaf;
+                for (uint32_t k = 0; k < nc_leaf; k++) pc[k] = src[k];
+            }
+        }
+    }
+    if (Lc && j == 0 && grp < per_block) {
+        CapGroup& d = capgrp[grp];
+        d.active = live ? 1u : 0u;
+        if (live) {
+            d.hw = hw; d.hw_n = hw_n; d.lvl = h->lvl; d.wf = nullptr; d.s_top = s_top;
+            d.root = w + W_COMMIT0 + 8 * t; d.flags = &a.ctxs[p].flags; d.fail_bit = R_MERKLE_T0 + t;
+        }
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
+        const uint32_t buf = lvl & 1u;
+        const bool on = live && lvl <= mx;
+        if (on) store_hash(xch[buf][threadIdx.x], cur);
+        __syncthreads();
+        if (on) {
+            uint32_t e = ent[lvl * G + j];
+            Hash8 sib;
+            if (ent_sib(e) != 0xFFu) sib = load_hash(xch[buf][gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
+                if (wi < hw_n) sib = load_hash(hw + 8 * wi);
+                else { sib = zero8(); bad = true; }
+            }
+            bool odd = (qj >> (M - lvl)) & 1u;
+            if (a.path_sib) {
+                const uint32_t oi = a.ctxs[p].qperm[j];
+                store_hash(a.path_sib + ((((size_t)slot_ * 4 + t) * G + oi) * a.pl.maxM + (mx - lvl)) * 8, sib);
+                if (lvl == mx) a.path_pos[((size_t)slot_ * 4 + t) * G + oi] = qj >> (M - mx);
+            }
+            cur = hash_tree_swap(cur, sib, odd);
+            const uint32_t pl_ = lvl - 1;  // parent level
+            uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));
+            if (nc) {
+                // lower-level rows were hashed counting from the end of queried_values
+                const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
+                const uint32_t off = nd_leaf * nc_leaf + row * nc;
+                if (off + nc > qv_n || nd_lower - 1 - row >= a.Grow) bad = true;
+                else {
+                    cur = combine_with_column(cur, load_hash(rows + ((size_t)a.Grow + (nd_lower - 1 - row)) * 8));
+                    if (a.path_cols) {
+                        uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64 + nc_leaf;
+                        const uint32_t* src = w + m->qv_off[t] + off;
+                        for (uint32_t k = 0; k < nc; k++) pc[k] = src[k];
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        // every witness hash and queried value must be consumed (components/hints/src/decommit.rs:141-142)
+        uint32_t lower = (t == 3 || A == B) ? 0u : umin(A, B);
+        uint32_t nc_lower = (t == 3 || A == B) ? 0u : (lower == A ? plonk_cols(t) : poseidon_cols(t));
+        uint32_t want_qv = nd_leaf * nc_leaf + (lower ? lvl_nd(h->lvl[lower]) * nc_lower : 0u);
+        uint32_t want_hw = lvl_s(h->lvl[1]) - s_top;
+        bool ok = !bad && want_qv == qv_n && want_hw == hw_n && (Lc || hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t)));
+        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (R_MERKLE_T0 + t));
+    }
+    if (Lc) {
+        uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
+        merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u);
+    }
+}
+
+// ------------------------------------------------------------ k_pair_merkle
+// SinglePairMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:400-464):
+// blockIdx.y = 0 is the FRI first-layer tree (one QM31 column at each distinct
+// column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
+    RSV_TAG(4);
+    __shared__ uint32_t xch[2][BLOCK][8];
+    __shared__ uint32_t xch2[BLOCK][8];  // path emission only: pre-column node hashes at data levels
+    __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
+    __shared__ CapGroup capgrp[64];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t slot_ = blockIdx.x * per_block + grp;
+    const uint32_t slot = blockIdx.y;
+    bool live = grp < per_block && slot_ < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq && (slot == 0 || slot - 1 < m->n_inner);
+    const uint32_t gbase = grp * G;
+    const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
+    const uint32_t* fl = nullptr; const uint32_t* leafv = nullptr; const ProofCtx* c = nullptr;
+    const FriLayerRef* L = nullptr;
+    uint32_t M = 0, top = 0, qj = 0, s_top = 0, dslot = 0;
+    bool bad = false, have_sib = false;
+    uint32_t* psib = nullptr;
+    Hash8 cur = zero8(), sibh = zero8();
+    if (live) {
+        w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+        ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
+        fl = a.pl.fl + (size_t)slot_ * 2 * G;
+        h = &a.pl.hdr[slot_];
+        c = &a.ctxs[p];
+        M = m->M;
+        L = slot == 0 ? &m->first : &m->inner[slot - 1];
+        top = slot == 0 ? M : M - slot;  // leaf level of this tree
+        qj = c->q[j];
+        s_top = lvl_s(h->lvl[top]);
+        leafv = a.leafv + ((size_t)slot_ * (3 + a.maxInner)) * G * 8;
+        const uint32_t* lv = leafv + ((size_t)(slot == 0 ? 0 : 2 + slot) * G + j) * 8;
+        cur = leaf_from_capacity(sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
+        sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+        have_sib = true;
+        dslot = 0;
+        if (a.pair_sib) {
+            const uint32_t oi = c->qperm[j];
+            const size_t row = ((size_t)slot_ * (1 + a.maxInner) + slot) * G + oi;
+            psib = a.pair_sib + row * a.pl.maxM * 8;
+            uint32_t* pc = a.pair_cols + row * 3 * 8;
+            const uint32_t nlev = slot == 0 ? c->n_sizes : 1u;
+            for (uint32_t g = 0; g < nlev; g++) {
+                const uint32_t* src = leafv + ((size_t)(slot == 0 ? g : 2 + slot) * G + j) * 8;
+                for (int k = 0; k < 8; k++) pc[g * 8 + k] = src[k];
+            }
+        }
+    }
+    if (Lc && j == 0 && grp < per_block) {
+        CapGroup& d = capgrp[grp];
+        d.active = live ? 1u : 0u;
+        if (live) {
+            d.hw = w + L->hash_off; d.hw_n = L->hash_n; d.lvl = h->lvl; d.wf = slot == 0 ? h->wf : nullptr; d.s_top = s_top;
+            d.root = w + L->commit_off; d.flags = &a.ctxs[p].flags; d.fail_bit = slot == 0 ? R_FRI_FIRST : R_FRI_INNER;
+        }
+    }
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
+        const bool on = live && lvl <= top;
+        const uint32_t pl_ = lvl - 1;
+        // is the parent level a data level of the first-layer tree?
+        int dg = -1;
+        if (on && slot == 0)
+            for (uint32_t g = 1; g < c->n_sizes; g++)
+                if (c->sizes[g] == pl_) dg = (int)g;
+        // phase A: sibling hash at the child level
+        if (on && !have_sib) store_hash(xch[0][threadIdx.x], cur);
+        __syncthreads();
+        if (on) {
+            if (!have_sib) {
+                uint32_t e = ent[lvl * G + j];
+                if (ent_sib(e) != 0xFFu) sibh = load_hash(xch[0][gbase + ent_sib(e)]);
+                else {
+                    uint32_t wi;
+                    if (slot == 0) wi = dg >= 0 ? (fl[dslot * G + j] & 0xFFFFu) : (uint32_t)h->wf[lvl] + ent_lb(e);
+                    else wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
+                    if (wi < L->hash_n) sibh = load_hash(w + L->hash_off + 8 * wi);
+                    else { sibh = zero8(); bad = true; }
+                }
+            }
+            bool odd = (qj >> (M - lvl)) & 1u;
+            // sibling_hashes[top-1-lvl]: the sibling at a level without a column (data levels: stored in phase B)
+            if (psib && !have_sib) store_hash(psib + (size_t)(top - 1 - lvl) * 8, sibh);
+            cur = hash_tree_swap(cur, sibh, odd);
+            have_sib = false;
+        }
+        // phase B: data level of the first-layer tree: fold in the column and build the sibling node
+        if (on && dg >= 0) {
+            const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
+            if (a.pair_sib) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
+            cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
+            store_hash(xch[1][threadIdx.x], cur);
+        }
+        __syncthreads();
+        if (on && dg >= 0) {
+            const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
+            uint32_t w_sib = fl[dslot * G + j] >> 16;
+            if (w_sib == 0xFFFFu) {
+                uint32_t e = ent[pl_ * G + j];
+                if (ent_sib(e) != 0xFFu) {
+                    sibh = load_hash(xch[1][gbase + ent_sib(e)]);
+                    if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, load_hash(xch2[gbase + ent_sib(e)]));
+                } else bad = true;
+            } else if (w_sib + 1 < L->hash_n) {
+                Hash8 sn = hash_tree(load_hash(w + L->hash_off + 8 * w_sib), load_hash(w + L->hash_off + 8 * (w_sib + 1)));
+                if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, sn);
+                sibh = combine_with_column(sn, sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+            } else bad = true;
+            have_sib = true;
+            dslot++;
+        }
+    }
+    if (live) {
+        uint32_t want_hw = slot == 0 ? (uint32_t)h->wf_total : lvl_s(h->lvl[1]) - s_top;
+        bool ok = !bad && want_hw == L->hash_n && (Lc || hash_eq(cur, load_hash(w + L->commit_off)));
+        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER));
+    }
+    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u);
+}
+
+}  // namespace rsv

@@ -1,0 +1,437 @@
+// k_plan.hpp — decommitment plan (k_plan_par, k_plan), transcript export, query-independent quotient constants (k_qconst).  Part of the pipeline described in verify.hpp.
+#pragma once
+#include "verify_common.hpp"
+
+namespace rsv {
+
+// ------------------------------------------------------------------- k_plan
+// Sorts the query positions, derives the decommitment plan (who owns which
+// sibling, which witness index each lane consumes; see layout.hpp) and the
+// per-proof constants of the DEEP quotients
+// (components/recursive/answer/src/data_structures.rs:132-189).
+// The per-query stages address their workspace by SLOT (position inside the current launch) and the
+// per-proof records / the blob by PROOF index: proof = ids ? ids[slot] : p0 + slot.  A batch of mixed shapes
+// is bucketed by n_queries on the host so that every launch uses G = that bucket's n_queries lanes per proof.
+struct PlanPtrs {
+    PlanHdr* hdr;
+    uint32_t* ent;  // [slots][(maxM+1) * G]
+    uint32_t* fl;   // [slots][2 * G]
+    uint32_t G, maxM;
+    const uint32_t* ids;  // slot -> proof index (nullptr: proof = p0 + slot)
+    uint32_t p0;
+    __device__ uint32_t proof_of(uint32_t slot) const { return ids ? ids[slot] : p0 + slot; }
+};
+
+__device__ inline int sample_index(int t, int col, int s) {
+    if (t == 0) return S_T0 + col;
+    if (t == 1) return S_T1 + col;
+    if (t == 3) return S_T3 + col;
+    return S_T2 + (col < 4 ? col : col < 8 ? 4 + 2 * (col - 4) + s : col < 12 ? 12 + (col - 8) : 16 + 2 * (col - 12) + s);
+}
+
+__global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                             uint32_t n, const ProofMeta* __restrict__ metas,
+                                             ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+    __shared__ uint32_t sq[MAXQ][64];
+    __shared__ uint8_t sp[MAXQ][64];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t p = pl.proof_of(slot);
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t nq = m.nq, M = m.M, A = m.A, B = m.B, G = pl.G;
+    uint32_t flags = 0;
+    // query positions (primitives/query/src/lib.rs:19-38), sorted ascending.  The sorted list is walked
+    // M times below, so it lives in LDS (k-major: the 64 lanes of the block hit 64 different banks).
+#define SQ(k) sq[(k)][threadIdx.x]
+    for (uint32_t j = 0; j < nq; j++) {
+        uint32_t v = c.raw_q[j] & ((1u << M) - 1u);
+        uint32_t k = j;
+        while (k > 0 && SQ(k - 1) > v) { SQ(k) = SQ(k - 1); sp[k][threadIdx.x] = sp[k - 1][threadIdx.x]; k--; }
+        SQ(k) = v;
+        sp[k][threadIdx.x] = (uint8_t)j;
+    }
+    for (uint32_t j = 0; j < nq; j++) { c.q[j] = SQ(j); c.qperm[j] = sp[j][threadIdx.x]; }
+    for (uint32_t j = 0; j + 1 < nq; j++)
+        if (SQ(j) == SQ(j + 1)) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
+    // column log sizes, descending
+    uint32_t n_sizes = 0;
+    c.sizes[n_sizes++] = M;
+    if (A == B) c.sizes[n_sizes++] = A;
+    else { c.sizes[n_sizes++] = umax(A, B); c.sizes[n_sizes++] = umin(A, B); }
+    c.n_sizes = n_sizes;
+    if (n_sizes < 3) c.sizes[2] = 0;
+
+    PlanHdr& h = pl.hdr[slot];
+    uint32_t* ent = pl.ent + (size_t)slot * (pl.maxM + 1) * G;
+    uint32_t* fl = pl.fl + (size_t)slot * 2 * G;
+    // generic tables, node level l = M .. 1 (children of level l-1)
+    uint32_t suffix = 0;
+    h.lvl[M + 1] = 0;
+    for (uint32_t l = M; l >= 1; l--) {
+        uint32_t sh = M - l;  // node = q >> sh
+        uint32_t k = 0, nodes_before = 0, runs_lacking = 0;
+        while (k < nq) {
+            uint32_t a = k;
+            int split = -1;
+            while (k + 1 < nq) {
+                uint32_t x = SQ(k) ^ SQ(k + 1);
+                int d = x ? 31 - __clz(x) : -1;
+                if (d > (int)sh) break;
+                if (d == (int)sh) split = (int)k;
+                k++;
+            }
+            uint32_t bnd = k;
+            k++;
+            bool both = split >= 0;
+            for (uint32_t j = a; j <= bnd; j++) {
+                bool right = both && (int)j > split;
+                uint32_t rb = nodes_before + (right ? 1u : 0u);
+                uint32_t sib = both ? (right ? (uint32_t)split : (uint32_t)split + 1u) : 0xFFu;
+                ent[l * G + j] = rb | (runs_lacking << 8) | (sib << 16);
+            }
+            nodes_before += both ? 2u : 1u;
+            runs_lacking += both ? 0u : 1u;
+        }
+        suffix += runs_lacking;
+        h.lvl[l] = nodes_before | (runs_lacking << 8) | (suffix << 16);
+    }
+    for (uint32_t j = 0; j < nq; j++) ent[j] = 0xFFu << 16;
+    h.lvl[0] = 1u | (suffix << 16);
+    // first-layer fri_witness bases (components/hints/src/folding.rs:414-451)
+    {
+        uint32_t base = 0;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            c.fw_base[g] = base;
+            base += (h.lvl[c.sizes[g]] >> 8) & 0xFFu;
+        }
+        if (base != m.first.wit_n) flags |= 1u << R_FRI_FIRST;
+    }
+    // first-layer pair tree hash-witness plan (components/hints/src/folding.rs:107-206)
+    {
+        uint32_t wcount = 0, dslot = 0;
+        for (uint32_t l = M; l-- > 0;) {
+            h.wf[l + 1] = (uint16_t)wcount;
+            bool child_data = false, data = false;
+            for (uint32_t g = 0; g < n_sizes; g++) { child_data |= c.sizes[g] == l + 1; data |= c.sizes[g] == l; }
+            uint32_t sh = M - l;
+            uint32_t k = 0;
+            while (k < nq) {
+                uint32_t a = k;
+                uint32_t node = SQ(k) >> sh;
+                bool has_both_children = false;
+                while (k + 1 < nq && (SQ(k + 1) >> sh) == node) {
+                    if (((SQ(k) >> (sh - 1)) ^ (SQ(k + 1) >> (sh - 1))) & 1u) has_both_children = true;
+                    k++;
+                }
+                uint32_t bnd = k;
+                k++;
+                uint32_t lack = (!child_data && !has_both_children) ? 1u : 0u;
+                if (data) {
+                    bool sib_present = (a > 0 && (SQ(a - 1) >> sh) == (node ^ 1u)) ||
+                                       (bnd + 1 < nq && (SQ(bnd + 1) >> sh) == (node ^ 1u));
+                    uint32_t w_self = 0xFFFFu, w_sib = 0xFFFFu;
+                    if (node & 1u) {
+                        if (!sib_present) { w_sib = wcount; wcount += 2; }
+                        if (lack) { w_self = wcount; wcount += 1; }
+                    } else {
+                        if (lack) { w_self = wcount; wcount += 1; }
+                        if (!sib_present) { w_sib = wcount; wcount += 2; }
+                    }
+                    if (dslot < 2)
+                        for (uint32_t j = a; j <= bnd; j++) fl[dslot * G + j] = w_self | (w_sib << 16);
+                } else {
+                    wcount += lack;
+                }
+            }
+            if (data) dslot++;
+        }
+        h.wf[0] = (uint16_t)wcount;
+        h.wf_total = (uint16_t)umin(wcount, 0xFFFFu);
+    }
+    if (flags) atomicOr(&c.flags, flags);
+#undef SQ
+}
+
+// ------------------------------------------------------------------ k_plan_par
+// The same tables as k_plan, computed with one lane per (proof, query) like the other per-query kernels instead of
+// one lane per proof (whose serial walk over LDS costs ~0.2 ms of pure latency per launch).  Everything follows
+// from ONE family of bitmasks per proof: F[l] has bit j set when sorted query j is the first lane of a distinct
+// node at tree level l (node = q >> (M - l)).  With N_l(x) = popcount(F[l] & bits[0..x]):
+//   distinct nodes left of lane j at level l              N_l(j) - 1
+//   a parent (level l-1 node, lanes s..e) has both children   N_l(e) - N_l(s) == 1; the right child starts at the
+//                                                          one bit of F[l] & ~F[l-1] inside (s, e]
+//   parents left of s that lack a child                    2 * popc(F[l-1] & below(s)) - popc(F[l] & below(s))
+// The first-layer pair tree adds per-level witness weights (see k_plan); their prefix sums over the nodes of a level
+// are popcounts of the same masks, and the running total over levels is a 30-step scan done by one lane.
+struct M128 {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ M128 m128_below(uint32_t x) {  // bits [0, x), x <= 128
+    M128 r;
+    r.lo = x >= 64 ? ~0ull : ((1ull << x) - 1ull);
+    r.hi = x <= 64 ? 0ull : (x >= 128 ? ~0ull : ((1ull << (x - 64)) - 1ull));
+    return r;
+}
+__device__ __forceinline__ M128 m128_and(M128 a, M128 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ M128 m128_andn(M128 a, M128 b) { return {a.lo & ~b.lo, a.hi & ~b.hi}; }
+__device__ __forceinline__ uint32_t m128_pop(M128 a) { return (uint32_t)(__popcll(a.lo) + __popcll(a.hi)); }
+__device__ __forceinline__ uint32_t m128_popbelow(M128 a, uint32_t x) { return m128_pop(m128_and(a, m128_below(x))); }
+// highest set bit at or below x (the mask has bit 0 set), lowest set bit above x or `none`
+__device__ __forceinline__ uint32_t m128_last_le(M128 a, uint32_t x) {
+    M128 t = m128_and(a, m128_below(x + 1));
+    return t.hi ? 127u - (uint32_t)__clzll((long long)t.hi) : 63u - (uint32_t)__clzll((long long)t.lo);
+}
+__device__ __forceinline__ uint32_t m128_first_gt(M128 a, uint32_t x, uint32_t none) {
+    M128 t = m128_andn(a, m128_below(x + 1));
+    if (t.lo) return (uint32_t)__ffsll((long long)t.lo) - 1u;
+    if (t.hi) return 63u + (uint32_t)__ffsll((long long)t.hi);
+    return none;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                    uint32_t n, const ProofMeta* __restrict__ metas,
+                                                    ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+    __shared__ unsigned long long F[64][32][2];   // per_block <= 64 proofs, levels 0..30
+    __shared__ uint32_t raw[BLOCK], sq[BLOCK];
+    __shared__ uint8_t sp[BLOCK];
+    __shared__ uint32_t tl[64][32];               // per level: nodes | lacking << 8
+    __shared__ uint32_t tw[64][32];               // per node level: witness weight of the first-layer pair tree
+    __shared__ uint32_t wsum[64][32];             // wf[l + 1]
+    const uint32_t G = pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * per_block + grp;
+    bool livep = grp < per_block && slot < n;
+    const uint32_t p = livep ? pl.proof_of(slot) : 0u;
+    const ProofMeta* m = livep ? &metas[p] : nullptr;
+    livep = livep && m->reason == R_OK;
+    const uint32_t nq = livep ? m->nq : 0u, M = livep ? m->M : 1u, A = livep ? m->A : 0u, B = livep ? m->B : 0u;
+    const bool live = livep && j < nq;
+    ProofCtx* c = livep ? &ctxs[p] : nullptr;
+    const uint32_t gbase = grp * G;
+    for (uint32_t i = threadIdx.x; i < 64u * 32u * 2u; i += BLOCK) (&F[0][0][0])[i] = 0ull;
+    const uint32_t v0 = live ? (c->raw_q[j] & ((1u << M) - 1u)) : 0xFFFFFFFFu;
+    raw[threadIdx.x] = v0;
+    __syncthreads();
+    // rank sort (primitives/query/src/lib.rs:19-38): ties broken by transcript index, as the insertion sort does
+    if (live) {
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < nq; k++) {
+            const uint32_t vk = raw[gbase + k];
+            rank += (vk < v0 || (vk == v0 && k < j)) ? 1u : 0u;
+        }
+        sq[gbase + rank] = v0;
+        sp[gbase + rank] = (uint8_t)j;
+    }
+    __syncthreads();
+    uint32_t flags = 0;
+    const uint32_t v = live ? sq[gbase + j] : 0u;
+    if (live) {
+        c->q[j] = v;
+        c->qperm[j] = sp[gbase + j];
+        if (j + 1 < nq && sq[gbase + j + 1] == v) flags |= 1u << R_DUP_QUERY;  // answer/src/lib.rs:190-195
+        // lane j starts a new node at every level l >= M - (highest bit in which it differs from lane j-1)
+        uint32_t lstart = 0;
+        if (j > 0) {
+            const uint32_t x = v ^ sq[gbase + j - 1];
+            lstart = x ? M - (31u - (uint32_t)__clz((int)x)) : M + 1u;
+        }
+        for (uint32_t l = lstart; l <= M; l++) atomicOr(&F[grp][l][j >> 6], 1ull << (j & 63u));
+    }
+    __syncthreads();
+    auto mask = [&](uint32_t l) { return M128{F[grp][l][0], F[grp][l][1]}; };
+    // column log sizes, descending
+    uint32_t sizes[3] = {M, A == B ? A : umax(A, B), A == B ? 0u : umin(A, B)};
+    const uint32_t n_sizes = A == B ? 2u : 3u;
+    auto is_size = [&](uint32_t l) { return l == sizes[0] || l == sizes[1] || (n_sizes == 3 && l == sizes[2]); };
+    // per-level totals, levels dealt round-robin to the proof's lanes
+    if (live) {
+        for (uint32_t l = j; l <= M; l += nq) {
+            const M128 Fl = mask(l);
+            const uint32_t nodes = m128_pop(Fl);
+            uint32_t lacking = 0;
+            if (l >= 1) lacking = 2u * m128_pop(mask(l - 1)) - nodes;
+            tl[grp][l] = nodes | (lacking << 8);
+            if (l < M) {
+                const uint32_t both_total = m128_pop(m128_andn(mask(l + 1), Fl));
+                const uint32_t nosib_total = l == 0 ? 1u : m128_pop(mask(l - 1)) - m128_pop(m128_andn(Fl, mask(l - 1)));
+                tw[grp][l] = (is_size(l + 1) ? 0u : nodes - both_total) + (is_size(l) ? 2u * nosib_total : 0u);
+            }
+        }
+    }
+    __syncthreads();
+    PlanHdr* h = livep ? &pl.hdr[slot] : nullptr;
+    if (live && j == 0) {
+        uint32_t suffix = 0;
+        h->lvl[M + 1] = 0;
+        for (uint32_t l = M; l >= 1; l--) {
+            suffix += (tl[grp][l] >> 8) & 0xFFu;
+            h->lvl[l] = tl[grp][l] | (suffix << 16);
+        }
+        h->lvl[0] = 1u | (suffix << 16);
+        uint32_t W = 0;
+        for (uint32_t l = M; l-- > 0;) {
+            wsum[grp][l] = W;
+            h->wf[l + 1] = (uint16_t)W;
+            W += tw[grp][l];
+        }
+        h->wf[0] = (uint16_t)W;
+        h->wf_total = (uint16_t)umin(W, 0xFFFFu);
+        c->n_sizes = n_sizes;
+        c->sizes[0] = sizes[0]; c->sizes[1] = sizes[1]; c->sizes[2] = n_sizes == 3 ? sizes[2] : 0u;
+        // first-layer fri_witness bases (components/hints/src/folding.rs:414-451)
+        uint32_t base = 0;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            c->fw_base[g] = base;
+            base += (tl[grp][sizes[g]] >> 8) & 0xFFu;
+        }
+        if (base != m->first.wit_n) flags |= 1u << R_FRI_FIRST;
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t* ent = pl.ent + (size_t)slot * (pl.maxM + 1) * G;
+        uint32_t* fl = pl.fl + (size_t)slot * 2 * G;
+        ent[j] = 0xFFu << 16;
+        for (uint32_t l = 1; l <= M; l++) {
+            const M128 Fl = mask(l), Fp = mask(l - 1);
+            const uint32_t s = m128_last_le(Fp, j);                     // first lane of my parent's run
+            const uint32_t e = m128_first_gt(Fp, j, nq) - 1u;           // its last lane
+            const uint32_t Ns = m128_popbelow(Fl, s + 1), Ne = m128_popbelow(Fl, e + 1), Nj = m128_popbelow(Fl, j + 1);
+            const bool both = Ne - Ns == 1u;
+            const bool right = both && Nj - Ns == 1u;
+            const uint32_t second = both ? m128_first_gt(Fl, s, nq) : 0u;  // first lane of the right child
+            const uint32_t sib = both ? (right ? second - 1u : second) : 0xFFu;
+            const uint32_t lack_before = 2u * m128_popbelow(Fp, s) - m128_popbelow(Fl, s);
+            ent[l * G + j] = (Nj - 1u) | (lack_before << 8) | (sib << 16);
+        }
+        // first-layer pair tree: witness indices at the (up to two) non-leaf column levels (folding.rs:107-206)
+        for (uint32_t d = 0; d + 1 < n_sizes; d++) {
+            const uint32_t l = sizes[1 + d];
+            if (l >= M) continue;
+            const M128 Fl = mask(l), Fc = mask(l + 1);
+            const uint32_t f = m128_last_le(Fl, j), e = m128_first_gt(Fl, j, nq) - 1u;
+            const bool has_both = m128_popbelow(Fc, e + 1) - m128_popbelow(Fc, f + 1) == 1u;
+            const bool child_data = is_size(l + 1);
+            const bool lack = !child_data && !has_both;
+            bool sib_present = false;
+            uint32_t nosib_before = 0;
+            if (l >= 1) {
+                const M128 Fp = mask(l - 1);
+                const uint32_t s = m128_last_le(Fp, j), pe = m128_first_gt(Fp, j, nq) - 1u;
+                sib_present = m128_popbelow(Fl, pe + 1) - m128_popbelow(Fl, s + 1) == 1u;
+                nosib_before = m128_popbelow(Fp, s) - m128_popbelow(m128_andn(Fl, Fp), s);
+            }
+            const uint32_t nodes_before = m128_popbelow(Fl, f), both_before = m128_popbelow(m128_andn(Fc, Fl), f);
+            const uint32_t base = wsum[grp][l] + (child_data ? 0u : nodes_before - both_before) + 2u * nosib_before;
+            const bool odd = (v >> (M - l)) & 1u;
+            uint32_t w_self = 0xFFFFu, w_sib = 0xFFFFu;
+            if (odd) {
+                if (!sib_present) w_sib = base;
+                if (lack) w_self = base + (sib_present ? 0u : 2u);
+            } else {
+                if (lack) w_self = base;
+                if (!sib_present) w_sib = base + (lack ? 1u : 0u);
+            }
+            fl[d * G + j] = (w_self & 0xFFFFu) | (w_sib << 16);
+        }
+    }
+    if (flags) atomicOr(&c->flags, flags);
+}
+
+// ------------------------------------------------------------------ k_export_transcript
+// One lane per output word: ProofCtx -> the flat row layout of include/rsv.h (RSV_TRANSCRIPT_WORDS).
+constexpr uint32_t TR_WORDS = 40 + 4 * (MAX_INNER + 1) + MAXQ;
+__global__ __launch_bounds__(256) void k_export_transcript(uint32_t n, const ProofMeta* __restrict__ metas,
+                                                            const ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * TR_WORDS) return;
+    const uint32_t p = (uint32_t)(gid / TR_WORDS), k = (uint32_t)(gid % TR_WORDS);
+    const ProofMeta& m = metas[p];
+    const ProofCtx& c = ctxs[p];
+    uint32_t v = 0;
+    if (m.reason != R_OK) v = k == 0 ? (uint32_t)R_PARSE : 0u;
+    else if (k == 0) v = (c.flags & (1u << R_POW)) ? (uint32_t)R_POW : (uint32_t)R_OK;
+    else if (k == 1) v = m.n_inner + 1;
+    else if (k == 2) v = m.nq;
+    else if (k == 3) v = m.M;
+    else if (k < 8) v = c.z[k - 4];
+    else if (k < 12) v = c.alpha[k - 8];
+    else if (k < 16) v = c.rc[k - 12];
+    else if (k < 20) v = c.oods_t[k - 16];
+    else if (k < 24) v = c.oods_x[k - 20];
+    else if (k < 28) v = c.oods_y[k - 24];
+    else if (k < 32) v = c.after[k - 28];
+    else if (k < 40) v = c.pow_digest[k - 32];
+    else if (k < 40 + 4 * (MAX_INNER + 1)) { uint32_t a = (k - 40) >> 2; v = a <= m.n_inner ? c.fri_alpha[a][(k - 40) & 3] : 0u; }
+    else { uint32_t q = k - (40 + 4 * (MAX_INNER + 1)); v = q < m.nq ? c.raw_q[q] : 0u; }
+    out[gid] = v;
+}
+
+// ------------------------------------------------------------------ k_qconst
+// One lane per proof: the query-independent constants of the DEEP quotients — alpha powers and, per column
+// log size and sample point, the summed line coefficients.  Needs only the transcript, so it runs on the side
+// stream next to k_plan (whose tables need only the query positions).
+__global__ __launch_bounds__(64) void k_qconst(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                               uint32_t n, const ProofMeta* __restrict__ metas,
+                                               ProofCtx* __restrict__ ctxs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const uint32_t M = m.M, A = m.A, B = m.B;
+    // column log sizes, descending (the same list k_plan stores in ProofCtx::sizes)
+    uint32_t sizes[3] = {M, A == B ? A : umax(A, B), A == B ? 0u : umin(A, B)};
+    const uint32_t n_sizes = A == B ? 2u : 3u;
+    // quotient constants: alpha_k = -2u * after^k (data_structures.rs:162-189)
+    QM31 after = ldq(c.after);
+    {
+        QM31 ak = q_mk(0, 0, m_neg(2), 0);
+#pragma unroll 1
+        for (int k = 0; k < N_APOW; k++) { stq(c.apow[k], ak); ak = q_mul(ak, after); }
+    }
+    QM31 ox = ldq(c.oods_x), oy = ldq(c.oods_y);
+    for (uint32_t g = 0; g < n_sizes; g++) {
+        uint32_t l = sizes[g];
+        // batch 0: OODS point; batch 1: OODS - g_{component log size} (answer/src/lib.rs:62-72)
+        uint32_t comp_log = (l == A) ? m.lp : m.lq;
+        CPoint step = cp_gen_mul(1u << (31u - comp_log));
+        step.y = m_neg(step.y);
+        QM31 sx = q_sub(q_mul_m(ox, step.x), q_mul_m(oy, step.y));
+        QM31 sy = q_add(q_mul_m(ox, step.y), q_mul_m(oy, step.x));
+        uint32_t k_run = 0, n_batches = (l == M) ? 1u : 2u;
+        for (uint32_t bi = 0; bi < n_batches; bi++) {
+            QM31 px = bi ? sx : ox, py = bi ? sy : oy;
+            QM31 sa = q_zero(), sb = q_zero();
+            for (int t = 0; t < 4; t++) {
+                uint32_t c0, c1;
+                if (l == M) { if (t != 3) continue; c0 = 0; c1 = 8; }
+                else {
+                    if (t == 3) continue;
+                    c0 = (l == A) ? 0u : plonk_cols(t);
+                    c1 = (l == B) ? tree_cols(t) : plonk_cols(t);
+                }
+                for (uint32_t col = c0; col < c1; col++) {
+                    uint32_t ns = n_samples_of(t, (int)col);
+                    if (bi == 1 && ns != 2) continue;
+                    int si = sample_index(t, (int)col, bi == 1 ? 0 : (int)ns - 1);
+                    QM31 v = ldq(w + SAMPLES.off[si]);
+                    QM31 ak = ldq(c.apow[k_run++]);
+                    // complex_conjugate_line_coeffs_var (data_structures.rs:132-160)
+                    sa = q_add(sa, q_mul_c(ak, v.b));
+                    sb = q_add(sb, q_mul_c(ak, c_sub(c_mul(v.a, py.b), c_mul(v.b, py.a))));
+                }
+            }
+            QBatch& qb = c.batch[g][bi];
+            stq(qb.sa, sa); stq(qb.sb, sb);
+            qb.prx[0] = px.a.a; qb.prx[1] = px.a.b; qb.pix[0] = px.b.a; qb.pix[1] = px.b.b;
+            qb.pry[0] = py.a.a; qb.pry[1] = py.a.b; qb.piy[0] = py.b.a; qb.piy[1] = py.b.b;
+        }
+        c.n_batches[g] = n_batches;
+    }
+}
+
+}  // namespace rsv

@@ -1,0 +1,275 @@
+// k_query.hpp — DEEP quotients, FRI folds, last-layer evaluation per query (k_query) and the arithmetic probes.  Part of the pipeline described in verify.hpp.
+#pragma once
+#include "k_plan.hpp"
+
+namespace rsv {
+
+// ------------------------------------------------------------------ k_query
+// One lane per (proof, query): DEEP quotients for every column log size
+// (answer/src/lib.rs:260-315,356-382), the circle->line fold of the first FRI
+// layer (folding/src/lib.rs:57-90), the line folds of the inner layers
+// (:120-192) and the last-layer polynomial check (:194-204).  Values owned by
+// other queries of the same proof (pair siblings) are exchanged through LDS.
+// Writes, for the Merkle kernels, the (self, sibling) leaf values of every FRI tree.
+struct QueryArgs {
+    const uint8_t* blob;
+    const uint64_t* offsets;
+    uint32_t n;
+    const ProofMeta* metas;
+    ProofCtx* ctxs;
+    PlanPtrs pl;
+    uint32_t* leafv;  // [n][3 + maxInner][G][8]
+    uint32_t maxInner;
+    uint32_t* folded_out;  // optional [n][3][G][4]: first-layer folds per size group, transcript query order
+};
+
+__device__ __forceinline__ uint32_t ent_rb(uint32_t e) { return e & 0xFFu; }
+__device__ __forceinline__ uint32_t ent_lb(uint32_t e) { return (e >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t ent_sib(uint32_t e) { return (e >> 16) & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_nd(uint32_t v) { return v & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_tl(uint32_t v) { return (v >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t lvl_s(uint32_t v) { return v >> 16; }
+
+__device__ inline QM31 fold_pair(QM31 self, QM31 sib, bool odd, uint32_t inv_coord, QM31 alpha) {
+    QM31 l = odd ? sib : self, r = odd ? self : sib;
+    return q_add(q_add(l, r), q_mul(q_mul_m(q_sub(l, r), inv_coord), alpha));
+}
+
+// LinePolyVar::eval_at_point (primitives/line/src/lib.rs:39-67): fold(coeffs, [x, pi(x), pi(pi(x)), ...]) with
+// fold(v, [f, rest]) = fold(v_lo, rest) + f * fold(v_hi, rest), i.e. sum_i coeff_i * prod_k d[k]^(bit (log_n-1-k) of i).
+// The weights factor into a table over the low 4 index bits (registers) times a product over the high bits.
+// cf: n = 2^log_n QM31 coefficients (4 words each).
+__device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x) {
+    uint32_t d[16];
+    for (uint32_t k = 0; k < 16; k++) { d[k] = (k < log_n) ? x : 1u; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+    const uint32_t nlo = log_n < 4 ? log_n : 4u;
+    uint32_t wl[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) wl[t] = 1u;
+    // low index bit b pairs with d[log_n - 1 - b]
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        uint32_t db = (uint32_t)b < nlo ? d[(log_n - 1 - b) & 15u] : 1u;
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (t & (1 << b)) wl[t] = m_mul(wl[t], db);
+    }
+    QM31 acc = q_zero();
+    const uint32_t n_hi = n >> nlo, n_lo = 1u << nlo;
+#pragma unroll 1
+    for (uint32_t hi = 0; hi < n_hi; hi++) {
+        uint32_t wh = 1u;
+        for (uint32_t b = 0; b + nlo < log_n; b++)
+            if ((hi >> b) & 1u) wh = m_mul(wh, d[(log_n - 1 - nlo - b) & 15u]);
+        QM31 inner = q_zero();
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if ((uint32_t)t < n_lo) inner = q_add(inner, q_mul_m(ldq(cf + 4 * ((hi << nlo) + t)), wl[t]));
+        acc = q_add(acc, q_mul_m(inner, wh));
+    }
+    return acc;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
+    __shared__ uint32_t xq[BLOCK][4];
+    const uint32_t G = a.pl.G, per_block = BLOCK / G;
+    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * per_block + grp;
+    bool live = grp < per_block && slot < a.n;
+    const uint32_t p = live ? a.pl.proof_of(slot) : 0u;
+    const ProofMeta* m = live ? &a.metas[p] : nullptr;
+    live = live && m->reason == R_OK && j < m->nq;
+    ProofCtx* c = live ? &a.ctxs[p] : nullptr;
+    const uint32_t* w = live ? reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]) : nullptr;
+    const uint32_t* ent = live ? a.pl.ent + (size_t)slot * (a.pl.maxM + 1) * G : nullptr;
+    const PlanHdr* h = live ? &a.pl.hdr[slot] : nullptr;
+    uint32_t* leafv = live ? a.leafv + ((size_t)slot * (3 + a.maxInner)) * G * 8 : nullptr;
+    const uint32_t gbase = grp * G;
+    uint32_t flags = 0;
+    uint32_t M = live ? m->M : 0, A = live ? m->A : 0, B = live ? m->B : 0;
+    uint32_t qj = live ? c->q[j] : 0;
+    uint32_t n_sizes = live ? c->n_sizes : 0;
+    QM31 first[3];
+    // Domain points.  One scalar multiplication gives the point of the query at level M; the points at the
+    // smaller column sizes follow by the doubling map pi(x, y) = (2x^2 - 1, 2xy): doubling the level-l point of
+    // position pos gives the level-(l-1) point of pos >> 1 up to the sign of y, which is fixed by bit 0 of the
+    // respective positions (CanonicCoset::circle_domain().at(bit_reverse(.))).
+    CPoint dp[3];
+    if (live) {
+        CPoint cur = domain_point(M, qj);
+        uint32_t lvl = M;
+        for (uint32_t g = 0; g < n_sizes; g++) {
+            const uint32_t l = c->sizes[g];
+            while (lvl > l) {
+                const uint32_t pos = qj >> (M - lvl);
+                uint32_t y2 = m_dbl(m_mul(cur.x, cur.y));
+                cur.x = m_sub(m_dbl(m_sqr(cur.x)), 1u);
+                cur.y = ((pos ^ (pos >> 1)) & 1u) ? m_neg(y2) : y2;
+                lvl--;
+            }
+            dp[g] = cur;
+        }
+    }
+    // ---- DEEP quotients + first-layer fold, per column log size
+    for (uint32_t g = 0; g < 3; g++) {
+        QM31 answer = q_zero();
+        uint32_t l = 0, pos = 0;
+        bool on = live && g < n_sizes;
+        if (on) {
+            l = c->sizes[g];
+            pos = qj >> (M - l);
+            QM31 r0 = q_zero(), r1 = q_zero();
+            uint32_t col = 0, dbl = 0;
+            const uint32_t ncols_group = (l == M) ? 8u : ((l == A ? 30u : 0u) + (l == B ? 96u : 0u));
+            for (int t = 0; t < 4; t++) {
+                if ((l == M) != (t == 3)) continue;
+                const uint32_t mx = (t == 3) ? M : umax(A, B);
+                const uint32_t nc_leaf = (t == 3) ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+                const uint32_t* qv = w + m->qv_off[t];
+                const uint32_t qv_n = m->qv_n[t];
+                // the two components' columns of this tree at level l
+                for (int comp = 0; comp < 2; comp++) {
+                    uint32_t cl = (t == 3) ? M : (comp == 0 ? A : B);
+                    if (cl != l) continue;
+                    uint32_t nc = (t == 3) ? (comp == 0 ? 8u : 0u) : (comp == 0 ? plonk_cols(t) : poseidon_cols(t));
+                    if (nc == 0) continue;
+                    uint32_t off;
+                    if (cl == mx) off = ent_rb(ent[mx * G + j]) * nc_leaf + ((comp == 1 && A == B && t != 3) ? plonk_cols(t) : 0u);
+                    else off = lvl_nd(h->lvl[mx]) * nc_leaf + ent_rb(ent[cl * G + j]) * nc;
+                    bool inb = off + nc <= qv_n;
+                    if (!inb) flags |= 1u << (R_MERKLE_T0 + t);
+                    for (uint32_t k = 0; k < nc; k++) {
+                        uint32_t v = inb ? qv[off + k] : 0u;
+                        r0 = q_add(r0, q_mul_m(ldq(c->apow[col]), v));
+                        if (t == 2 && (k & 4)) {
+                            r1 = q_add(r1, q_mul_m(ldq(c->apow[ncols_group + dbl]), v));
+                            dbl++;
+                        }
+                        col++;
+                    }
+                }
+            }
+            for (uint32_t bi = 0; bi < c->n_batches[g]; bi++) {
+                const QBatch& qb = c->batch[g][bi];
+                CM31 prx = c_mk(qb.prx[0], qb.prx[1]), pix = c_mk(qb.pix[0], qb.pix[1]);
+                CM31 pry = c_mk(qb.pry[0], qb.pry[1]), piy = c_mk(qb.piy[0], qb.piy[1]);
+                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dp[g].y), ldq(qb.sb)));
+                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dp[g].x, 0)), piy), c_mul(c_sub(pry, c_mk(dp[g].y, 0)), pix));
+                answer = q_add(answer, q_mul_c(num, c_inv(den)));
+            }
+        }
+        // exchange answers: the pair sibling may be another query of this proof
+        stq(xq[threadIdx.x], answer);
+        __syncthreads();
+        if (on) {
+            uint32_t e = ent[l * G + j];
+            QM31 sib;
+            if (ent_sib(e) != 0xFFu) sib = ldq(xq[gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = c->fw_base[g] + ent_lb(e);
+                sib = wi < m->first.wit_n ? ldq(w + m->first.wit_off + 4 * wi) : q_zero();
+            }
+            uint32_t* lv = leafv + ((size_t)g * G + j) * 8;
+            stq(lv, answer); stq(lv + 4, sib);
+            // fold circle -> line with 1/y of the pair's base point (folding/src/lib.rs:57-90); the base
+            // point (bit 0 of the position cleared) is the conjugate of this point when the position is odd
+            uint32_t by = (pos & 1u) ? m_neg(dp[g].y) : dp[g].y;
+            first[g] = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
+            if (a.folded_out) stq(a.folded_out + (((size_t)slot * 3 + g) * G + c->qperm[j]) * 4, first[g]);
+        }
+        __syncthreads();
+    }
+    // ---- inner layers (folding/src/lib.rs:120-192)
+    // x-coordinate of the pair base point at line-domain level l: X_{M-1} = +-x_M and X_{l-1} = +-(2 X_l^2 - 1)
+    // (half_odds(l).at(i) doubles to half_odds(l-1).at(i mod 2^(l-1)); clearing bit 0 of an odd position moves
+    // the bit-reversed index by half the coset = the point (-1, 0), i.e. negates x).
+    QM31 folded = q_zero();
+    uint32_t l = M;
+    uint32_t X = live ? dp[0].x : 0u;
+    for (uint32_t i = 0; i < a.maxInner; i++) {
+        bool on = live && i < m->n_inner;
+        if (on) {
+            for (uint32_t g = 0; g < n_sizes; g++)
+                if (c->sizes[g] == l) {
+                    QM31 al = ldq(c->fri_alpha[i]);
+                    folded = q_add(q_mul(q_mul(al, al), folded), first[g]);
+                }
+            l -= 1;
+        }
+        stq(xq[threadIdx.x], folded);
+        __syncthreads();
+        if (on) {
+            uint32_t pos = qj >> (M - l);
+            uint32_t e = ent[l * G + j];
+            const FriLayerRef& L = m->inner[i];
+            QM31 sib;
+            if (ent_sib(e) != 0xFFu) sib = ldq(xq[gbase + ent_sib(e)]);
+            else {
+                uint32_t wi = ent_lb(e);
+                sib = wi < L.wit_n ? ldq(w + L.wit_off + 4 * wi) : q_zero();
+            }
+            if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= 1u << R_FRI_INNER;  // hints/src/folding.rs:558
+            uint32_t* lv = leafv + ((size_t)(3 + i) * G + j) * 8;
+            stq(lv, folded); stq(lv + 4, sib);
+            uint32_t xr = (i == 0) ? X : m_sub(m_dbl(m_sqr(X)), 1u);
+            X = (pos & 1u) ? m_neg(xr) : xr;
+            folded = fold_pair(folded, sib, pos & 1u, m_inv(X), ldq(c->fri_alpha[i + 1]));
+        }
+        __syncthreads();
+    }
+    // ---- last layer (folding/src/lib.rs:194-204, primitives/line/src/lib.rs:39-67)
+    if (live) {
+        // x of half_odds(l-1).at(bit_reverse(pos >> 1)) = pi(X_l) (for a proof without inner layers: pi of x_M)
+        QM31 acc = line_eval(w + m->last_off, m->log_last, m->last_n, m_sub(m_dbl(m_sqr(X)), 1u));
+        if (!q_eq(acc, folded)) flags |= 1u << R_FRI_LAST;
+    }
+    if (flags) atomicOr(&c->flags, flags);
+}
+
+// ------------------------------------------------------------------ probes
+// Batch probes of the arithmetic the verify kernels are made of (include/rsv.h: rsv_field_op, rsv_domain_points,
+// rsv_line_eval): the SAME device functions, one lane per item, so that each can be checked on its own
+// (SURVEY rows a1, a2, a8 and the last layer of a12).
+__global__ __launch_bounds__(256) void k_field_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                   uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    QM31 x = ldq(a + 4 * i), y = b ? ldq(b + 4 * i) : q_zero(), r = q_zero();
+    switch (op) {
+        case 0: r = q_add(x, y); break;
+        case 1: r = q_sub(x, y); break;
+        case 2: r = q_mul(x, y); break;
+        case 3: r = q_inv(x); break;
+        case 4: r = q_mk(m_mul(x.a.a, y.a.a), 0, 0, 0); break;           // M31 product of the first words
+        case 5: r = q_mk(m_inv(x.a.a), 0, 0, 0); break;                  // M31 inverse of the first word
+        case 6: { CM31 c = c_mul(x.a, y.a); r = q_mk(c.a, c.b, 0, 0); } break;
+        case 7: { CM31 c = c_inv(x.a); r = q_mk(c.a, c.b, 0, 0); } break;
+        case 8: r = q_mul_i(x); break;
+        case 9: r = q_mul_u(x); break;
+        case 10: {                                                       // x^e, e = first word of y (QM31Var::pow)
+            QM31 acc = q_one(), base = x;
+            for (uint32_t e = y.a.a; e; e >>= 1) { if (e & 1u) acc = q_mul(acc, base); base = q_mul(base, base); }
+            r = acc;
+        } break;
+        default: break;
+    }
+    stq(out + 4 * i, r);
+}
+
+__global__ __launch_bounds__(256) void k_domain_points(uint32_t log_size, const uint32_t* __restrict__ q,
+                                                        uint32_t* __restrict__ xy, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    CPoint p = domain_point(log_size, q[i] & ((1u << log_size) - 1u));
+    xy[2 * i] = p.x; xy[2 * i + 1] = p.y;
+}
+
+__global__ __launch_bounds__(256) void k_line_eval(const uint32_t* __restrict__ coeffs, uint32_t log_n,
+                                                    const uint32_t* __restrict__ x, uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    stq(out + 4 * i, line_eval(coeffs, log_n, 1u << log_n, x[i]));
+}
+
+}  // namespace rsv

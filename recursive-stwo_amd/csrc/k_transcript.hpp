@@ -1,0 +1,167 @@
+// k_transcript.hpp — Fiat-Shamir transcript: lane form (k_transcript) and DPP-row form (k_transcript_row).  Part of the pipeline described in verify.hpp.
+#pragma once
+#include "verify_common.hpp"
+
+namespace rsv {
+
+// ------------------------------------------------------------- k_transcript
+// FiatShamirResults::compute (components/recursive/fiat_shamir/src/lib.rs:44-130):
+// a strictly sequential chain of channel permutations per proof.
+__global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                   uint32_t n, const ProofMeta* __restrict__ metas,
+                                                   ProofCtx* __restrict__ ctxs) {
+    RSV_TAG(1);
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    Channel ch;
+    ch.init();
+    Hash8 d;
+    ch.mix(load_hash(w + W_COMMIT0));
+    ch.mix_one(q_from_m(m.lp));  // statement 0: data_structures/src/lib.rs:52-55
+    ch.mix_one(q_from_m(m.lq));
+    ch.mix(load_hash(w + W_COMMIT0 + 8));
+    d = ch.draw();  // lookup elements z, alpha: data_structures/src/lib.rs:242-245
+    stq(c.z, q_lo(d)); stq(c.alpha, q_hi(d));
+    ch.mix_two(ldq(w + W_PLONK_SUM), ldq(w + W_POSEIDON_SUM));  // statement 1: data_structures/src/lib.rs:85-87
+    ch.mix(load_hash(w + W_COMMIT0 + 16));
+    d = ch.draw();
+    stq(c.rc, q_lo(d));
+    ch.mix(load_hash(w + W_COMMIT0 + 24));
+    d = ch.draw();
+    QM31 t = q_lo(d);
+    stq(c.oods_t, t);
+    {  // CirclePointQM31Var::from_t (primitives/circle/src/lib.rs:204-219)
+        QM31 t2 = q_mul(t, t);
+        QM31 inv = q_inv(q_add(t2, q_one()));
+        stq(c.oods_x, q_mul(q_sub(q_one(), t2), inv));
+        stq(c.oods_y, q_mul(q_dbl(t), inv));
+    }
+#pragma unroll 1
+    for (int k = 0; k < N_SAMPLES; k += 2)  // fiat_shamir/src/lib.rs:68-75
+        ch.mix_two(ldq(w + SAMPLES.off[k]), ldq(w + SAMPLES.off[k + 1]));
+    d = ch.draw();
+    stq(c.after, q_lo(d));
+    ch.mix(load_hash(w + m.first.commit_off));
+    d = ch.draw();
+    stq(c.fri_alpha[0], q_lo(d));
+#pragma unroll 1
+    for (uint32_t i = 0; i < m.n_inner; i++) {
+        ch.mix(load_hash(w + m.inner[i].commit_off));
+        d = ch.draw();
+        stq(c.fri_alpha[i + 1], q_lo(d));
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < m.last_n; i += 2) {  // fiat_shamir/src/lib.rs:94-100
+        const uint32_t* cf = w + m.last_off + 4 * i;
+        if (i + 1 < m.last_n) ch.mix_two(ldq(cf), ldq(cf + 4));
+        else ch.mix_one(ldq(cf));
+    }
+    // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
+    uint64_t nonce = (uint64_t)w[m.nonce_off] | ((uint64_t)w[m.nonce_off + 1] << 32);
+    ch.mix_one(q_mk((uint32_t)(nonce & ((1u << 22) - 1)), (uint32_t)((nonce >> 22) & ((1u << 21) - 1)),
+                    (uint32_t)((nonce >> 43) & ((1u << 21) - 1)), 0));
+    store_hash(c.pow_digest, ch.digest);
+    uint32_t flags = 0;
+    if (ch.digest.w[0] & ((1u << m.pow_bits) - 1u)) flags |= 1u << R_POW;  // fiat_shamir/src/lib.rs:115-117
+    uint32_t got = 0;  // fiat_shamir/src/lib.rs:119-130
+#pragma unroll 1
+    while (got < m.nq) {
+        d = ch.draw();
+        for (int k = 0; k < 8 && got < m.nq; k++) c.raw_q[got++] = d.w[k];
+    }
+    c.flags = flags;
+}
+
+// --------------------------------------------------------- k_transcript_row
+// The same transcript with ONE PROOF PER 16-LANE ROW (poseidon2_row.hpp): lane i holds state word i, lanes
+// 0..7 are the rate half (what is mixed in / drawn), lanes 8..15 the capacity half, i.e. the channel digest
+// (primitives/channel/src/lib.rs:30-58).  A permutation is ~4x shorter in latency and ~4x dearer in issue
+// slots than in k_transcript, so the host uses this kernel for small batches, where the 233-step chain —
+// not throughput — is the cost.
+__global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                        uint32_t n, const ProofMeta* __restrict__ metas,
+                                                        ProofCtx* __restrict__ ctxs) {
+    const uint32_t i = threadIdx.x & 15u;
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (p >= n) return;  // whole rows leave together (DPP needs every lane of a live row)
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const bool rate = i < 8;
+    uint32_t dg = 0, n_sent = 0;
+    // mix: digest = perm(left || digest)[8..16]
+    auto mix = [&](uint32_t left_word) {
+        uint32_t out = poseidon2_row(rate ? left_word : dg, i);
+        if (!rate) dg = out;
+        n_sent = 0;
+    };
+    // draw: perm([n_sent, 0 x 7] || digest)[0..8]; the digest is not advanced
+    auto draw = [&]() {
+        uint32_t out = poseidon2_row(rate ? (i == 0 ? n_sent : 0u) : dg, i);
+        n_sent++;
+        return out;
+    };
+    auto mix_words = [&](const uint32_t* src, uint32_t n_words) { mix((rate && i < n_words) ? src[i] : 0u); };
+    auto store_felt = [&](uint32_t* dst, uint32_t out) { if (i < 4) dst[i] = out; };
+    uint32_t out;
+    mix_words(w + W_COMMIT0, 8);
+    mix(i == 0 ? m.lp : 0u);  // statement 0: data_structures/src/lib.rs:52-55
+    mix(i == 0 ? m.lq : 0u);
+    mix_words(w + W_COMMIT0 + 8, 8);
+    out = draw();  // lookup elements z, alpha
+    if (i < 4) c.z[i] = out; else if (i < 8) c.alpha[i - 4] = out;
+    mix_words(w + W_PLONK_SUM, 8);  // statement 1: the two total sums are adjacent words 2..10
+    mix_words(w + W_COMMIT0 + 16, 8);
+    out = draw();
+    store_felt(c.rc, out);
+    mix_words(w + W_COMMIT0 + 24, 8);
+    out = draw();
+    store_felt(c.oods_t, out);
+    {  // CirclePointQM31Var::from_t (primitives/circle/src/lib.rs:204-219); every lane computes it
+        const int base = (int)((threadIdx.x & 63u) & ~15u);
+        QM31 t = q_mk(__shfl(out, base + 0), __shfl(out, base + 1), __shfl(out, base + 2), __shfl(out, base + 3));
+        QM31 t2 = q_mul(t, t);
+        QM31 inv = q_inv(q_add(t2, q_one()));
+        if (i == 0) {
+            stq(c.oods_x, q_mul(q_sub(q_one(), t2), inv));
+            stq(c.oods_y, q_mul(q_dbl(t), inv));
+        }
+    }
+#pragma unroll 1
+    for (int k = 0; k < N_SAMPLES; k += 2)  // fiat_shamir/src/lib.rs:68-75
+        mix(rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u);
+    out = draw();
+    store_felt(c.after, out);
+    mix_words(w + m.first.commit_off, 8);
+    out = draw();
+    store_felt(c.fri_alpha[0], out);
+#pragma unroll 1
+    for (uint32_t l = 0; l < m.n_inner; l++) {
+        mix_words(w + m.inner[l].commit_off, 8);
+        out = draw();
+        store_felt(c.fri_alpha[l + 1], out);
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; k < m.last_n; k += 2) {  // fiat_shamir/src/lib.rs:94-100 (odd tail: second felt = 0)
+        const uint32_t left = 4 * (m.last_n - k);
+        mix_words(w + m.last_off + 4 * k, left < 8 ? left : 8u);
+    }
+    // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
+    const uint64_t nonce = (uint64_t)w[m.nonce_off] | ((uint64_t)w[m.nonce_off + 1] << 32);
+    mix(i == 0 ? (uint32_t)(nonce & ((1u << 22) - 1)) : i == 1 ? (uint32_t)((nonce >> 22) & ((1u << 21) - 1))
+        : i == 2 ? (uint32_t)((nonce >> 43) & ((1u << 21) - 1)) : 0u);
+    if (!rate) c.pow_digest[i - 8] = dg;
+    if (i == 8) c.flags = (dg & ((1u << m.pow_bits) - 1u)) ? (1u << R_POW) : 0u;  // fiat_shamir/src/lib.rs:115-117
+#pragma unroll 1
+    for (uint32_t got = 0; got < m.nq; got += 8) {  // fiat_shamir/src/lib.rs:119-130
+        out = draw();
+        if (rate && got + i < m.nq) c.raw_q[got + i] = out;
+    }
+}
+
+}  // namespace rsv
