@@ -61,6 +61,15 @@ def test_half_permute(rsv):
         assert np.array_equal(rate, orate) and np.array_equal(cap, ocap)
 
 
+def test_half_permute_known_answer_with_swap(rsv):
+    """primitives/poseidon31/src/emulated.rs:236-275: the KAT through Poseidon2HalfVar::permute, three swap variants."""
+    kat = [260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083, 755063943, 1682438524, 1265420601, 238640995, 200799880, 1659717477, 2080202267, 1269806256, 1287849264]
+    lo, hi = np.arange(8, dtype=np.uint32)[None], np.arange(8, 16, dtype=np.uint32)[None]
+    for l, r, sw in ((lo, hi, None), (lo, hi, np.array([0], np.uint8)), (hi, lo, np.array([1], np.uint8))):
+        rate, cap = rsv.half_permute(l, r, sw)
+        assert np.concatenate([rate[0], cap[0]]).tolist() == kat
+
+
 @pytest.mark.parametrize("n_cols", [0, 1, 4, 7, 8, 13, 16, 17, 21, 25, 48])
 def test_hash_node(rsv, n_cols):
     # column lengths 7/13/16/17/21/25 are the ones primitives/merkle/src/lib.rs:207-303 tests
