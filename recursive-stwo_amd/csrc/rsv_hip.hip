@@ -154,8 +154,6 @@ int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out,
     // the range flag lives at the start of the workspace
     if (c->ws_bytes < 256) {
         if (c->ws) (void)hipFree(c->ws);
-    if (c->ws_fixed) (void)hipFree(c->ws_fixed);
-    if (c->ws_rows) (void)hipFree(c->ws_rows);
         c->ws = nullptr; c->ws_bytes = 0;
         HIP_TRY(hipMalloc(&c->ws, 1 << 20));
         c->ws_bytes = 1 << 20;
