@@ -1,0 +1,50 @@
+"""One-off soak: GPU verdict / reason against the oracle over a large mutant corpus of every Poseidon-channel fixture
+(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random]"""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rsvload  # noqa: E402
+from tests import oracle_binding as ob  # noqa: E402
+from tests.mutants import mutants_of  # noqa: E402
+
+rsv = rsvload.load_package()
+
+
+def main():
+    n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["proofs"]
+    rng = np.random.default_rng(2026)
+    batch = []
+    for e in man:
+        if [(i, tuple(v)) for i, v in e["inputs"]] != list(ob.STANDARD_INPUTS):
+            continue
+        proof = open(os.path.join(ROOT, "tests", "golden", "proofs", e["file"]), "rb").read()
+        batch += mutants_of(proof, rng, n_random) + [proof]
+    order = rng.permutation(len(batch))
+    batch = [batch[i] for i in order]
+    t0 = time.perf_counter()
+    acc, reason = rsv.verify_batch(batch)
+    t1 = time.perf_counter()
+    parts = np.array_split(np.arange(len(batch)), 16)
+    with ThreadPoolExecutor(16) as ex:
+        res = list(ex.map(lambda ix: ob.verify_batch([batch[i] for i in ix]), parts))
+    oacc = np.concatenate([r[0] for r in res])
+    oreason = np.concatenate([r[1] for r in res])
+    t2 = time.perf_counter()
+    diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
+    print(f"{len(batch)} proofs: GPU {t1 - t0:.2f} s (host path), oracle {t2 - t1:.1f} s; accepted {int(acc.sum())}; "
+          f"reasons {np.bincount(reason, minlength=13).tolist()}; mismatches {diff.size}")
+    for i in diff[:10]:
+        print("  mismatch", int(i), int(acc[i]), int(reason[i]), int(oacc[i]), int(oreason[i]), len(batch[i]))
+    sys.exit(1 if diff.size else 0)
+
+
+if __name__ == "__main__":
+    main()
