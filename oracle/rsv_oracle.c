@@ -485,6 +485,8 @@ typedef struct {
     int pow_ok;
 } transcript;
 
+static uint32_t sort_dedup(uint32_t* q, uint32_t n);
+static channel* g_pre_nonce; /* set by rsvo_grind_nonce around run_transcript */
 static void run_transcript(const proof_view* v, transcript* t) {
     channel ch; memset(&ch, 0, sizeof ch);
     qm31 dummy;
@@ -519,6 +521,7 @@ static void run_transcript(const proof_view* v, transcript* t) {
         if (i + 1 < v->n_last) ch_mix_two(&ch, q_mk(c[0], c[1], c[2], c[3]), q_mk(c[4], c[5], c[6], c[7]));
         else ch_mix_one(&ch, q_mk(c[0], c[1], c[2], c[3]));
     }
+    if (g_pre_nonce) *g_pre_nonce = ch; /* test helper rsvo_grind_nonce: channel state before the nonce is mixed */
     /* nonce split 22/21/21 bits: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113 */
     uint64_t n = v->pow_nonce;
     ch_mix_one(&ch, q_mk((m31)(n & ((1u << 22) - 1)), (m31)((n >> 22) & ((1u << 21) - 1)),
@@ -532,6 +535,46 @@ static void run_transcript(const proof_view* v, transcript* t) {
         uint32_t w[8] = {a.a.a, a.a.b, a.b.a, a.b.b, b2.a.a, b2.a.b, b2.b.a, b2.b.b};
         for (int i = 0; i < 8 && got < nq; i++) t->raw_queries[got++] = w[i];
     }
+}
+
+/* Test-vector helper (not part of the verify path): find a proof-of-work nonce >= start for the proof as it stands
+ * (e.g. after a test has changed a sampled value), optionally one whose query positions contain a duplicate, so
+ * that rejection paths BEHIND the proof-of-work check can be exercised.  Returns RSV_OK and *nonce, or RSV_E_SIZE
+ * when the proof does not parse / no nonce below start + max_tries qualifies. */
+int rsvo_grind_nonce(const uint8_t* proof, size_t len, uint64_t start, uint64_t max_tries, int want_duplicate_query,
+                     uint64_t* nonce) {
+    if (!proof || !nonce) return RSV_E_NULL;
+    proof_view* v = malloc(sizeof *v);
+    transcript* t = malloc(sizeof *t);
+    channel pre;
+    int rc = RSV_E_SIZE;
+    if (!parse_proof(proof, len, NULL, v)) goto done;
+    g_pre_nonce = &pre;
+    run_transcript(v, t);
+    g_pre_nonce = NULL;
+    const uint32_t mask = (1u << v->cfg.pow_bits) - 1, nq = v->cfg.n_queries, qmask = (1u << v->M) - 1;
+    for (uint64_t n = start; n < start + max_tries; n++) {
+        channel ch = pre;
+        ch_mix_one(&ch, q_mk((m31)(n & ((1u << 22) - 1)), (m31)((n >> 22) & ((1u << 21) - 1)),
+                             (m31)((n >> 43) & ((1u << 21) - 1)), 0));
+        if (ch.digest[0] & mask) continue;
+        if (want_duplicate_query) {
+            uint32_t q[MAX_QUERIES], got = 0;
+            while (got < nq) {
+                qm31 a, b2;
+                ch_draw(&ch, &a, &b2);
+                uint32_t w[8] = {a.a.a, a.a.b, a.b.a, a.b.b, b2.a.a, b2.a.b, b2.b.a, b2.b.b};
+                for (int i = 0; i < 8 && got < nq; i++) q[got++] = w[i] & qmask;
+            }
+            if (sort_dedup(q, nq) == nq) continue;
+        }
+        *nonce = n;
+        rc = RSV_OK;
+        break;
+    }
+done:
+    free(v); free(t);
+    return rc;
 }
 
 int rsvo_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap) {

@@ -31,6 +31,8 @@ int rsvo_merkle_hash_node(const uint32_t* left8, const uint32_t* right8,
 int rsvo_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint32_t* cols,
                           const uint32_t* n_cols_at, uint32_t depth, uint32_t* out_root8,
                           size_t n);
+int rsvo_grind_nonce(const uint8_t* proof, size_t len, uint64_t start, uint64_t max_tries, int want_duplicate_query,
+                     uint64_t* nonce);
 int rsvo_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap);
 int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
                       const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,

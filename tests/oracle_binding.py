@@ -202,6 +202,22 @@ def line_eval(coeffs, x):
     return out
 
 
+def grind_nonce(proof: bytes, want_duplicate_query: bool = False, start: int = 0, max_tries: int = 1 << 34) -> bytes:
+    """Re-grind the proof-of-work nonce of a (modified) proof so that it passes the PoW check again — optionally with a
+    duplicate query position — and return the patched proof.  Test-vector helper (rsvo_grind_nonce)."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    nonce = ctypes.c_uint64(0)
+    lib.rsvo_grind_nonce.restype = ctypes.c_int
+    lib.rsvo_grind_nonce.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    rc = lib.rsvo_grind_nonce(b.ctypes.data_as(_u8p), len(proof), start, max_tries, 1 if want_duplicate_query else 0, ctypes.byref(nonce))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_grind_nonce -> {rc}")
+    pos = 4 * proof_layout(proof)["nonce_word"]
+    out = bytearray(proof)
+    out[pos:pos + 8] = int(nonce.value).to_bytes(8, "little")
+    return bytes(out)
+
+
 def splitmix64(seed, i):
     """splitmix64 stream used for seeded tampering."""
     mask = (1 << 64) - 1
@@ -296,6 +312,7 @@ def proof_layout(proof: bytes):
     prefixes.append((pos, int(w[pos]), "queried_values")); pos += 2
     for t in range(4):
         nv = int(w[pos]); prefixes.append((pos, nv, f"queried_values[{t}]")); pos += 2 + nv
+    nonce_word = pos
     pos += 2  # proof-of-work nonce
     layers = []
 
@@ -313,7 +330,7 @@ def proof_layout(proof: bytes):
         layers.append(ci)
     prefixes.append((pos, int(w[pos]), "last_layer_poly"))
     return {"lp": int(w[0]), "lq": int(w[1]), "blowup": int(w[11]), "log_last": int(w[12]), "nq": int(w[13]),
-            "fri_commitments": layers, "n_inner": n_inner, "prefixes": prefixes}
+            "fri_commitments": layers, "n_inner": n_inner, "prefixes": prefixes, "nonce_word": nonce_word}
 
 
 def split_variable_part(proof: bytes):

@@ -568,3 +568,14 @@ def test_plan_kernels_serial_and_parallel(rsv, manifest, monkeypatch):
         monkeypatch.setenv("RSV_PLAN", mode)
         acc, reason = rsv.verify_batch(batch)
         assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), mode
+
+
+def test_reject_fixtures_behind_the_proof_of_work(rsv):
+    """Rejection stages that random corruption never reaches (it stops at the proof of work): the OODS composition
+    identity and the duplicate-query assertion, with the re-ground fixtures of tests/golden/make_reject_fixtures.py."""
+    inputs = [(1, (1, 0, 0, 0))]
+    batch = [read_proof("small_proof_composition.bin"), read_proof("small_proof.bin"), read_proof("small_proof_dup_query.bin")] * 3
+    acc, reason = rsv.verify_batch(batch, inputs)
+    oacc, oreason = ob.verify_batch(batch, inputs)
+    assert acc.tolist() == oacc.tolist() == [0, 1, 0] * 3
+    assert reason.tolist() == oreason.tolist() == [4, 0, 5] * 3

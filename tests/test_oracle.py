@@ -404,3 +404,20 @@ def test_line_eval_matches_fold_definition():
                 lo, hi = fold(vals[:half], f[1:]), fold(vals[half:], f[1:])
                 return [(lo[k] + hi[k] * f[0]) % P31 for k in range(4)]
             assert got[t].tolist() == fold(list(coeffs), d)
+
+
+def test_reject_fixtures_behind_the_proof_of_work():
+    """tests/golden/make_reject_fixtures.py: small_proof.bin with a changed sampled value / with a duplicate query
+    position, nonce re-ground so that the proof-of-work still passes -> RSV_R_COMPOSITION (4) and RSV_R_DUP_QUERY (5).
+    The un-reground variant of the first one stops at the proof of work (2)."""
+    inputs = [(1, (1, 0, 0, 0))]
+    comp, dup, good = read_proof("small_proof_composition.bin"), read_proof("small_proof_dup_query.bin"), read_proof("small_proof.bin")
+    lay = ob.proof_layout(good)
+    stale = bytearray(comp)
+    stale[4 * lay["nonce_word"]:4 * lay["nonce_word"] + 8] = good[4 * lay["nonce_word"]:4 * lay["nonce_word"] + 8]
+    acc, reason = ob.verify_batch([comp, dup, good, bytes(stale)], inputs)
+    assert acc.tolist() == [0, 0, 1, 0] and reason.tolist() == [4, 5, 0, 2]
+    # the duplicate really is one: the masked query positions of the re-ground transcript collide
+    t = ob.transcript_raw(dup)
+    q = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + 16] & ((1 << int(t[3])) - 1)
+    assert len(set(q.tolist())) < 16 and t[0] == 0
