@@ -22,7 +22,7 @@ struct State16 {
     uint32_t s[16];
 };
 
-__constant__ uint32_t RC_FULL[8][16] = {
+__constant__ __attribute__((aligned(64))) uint32_t RC_FULL[8][16] = {
     {0x768bab52, 0x70e0ab7d, 0x3d266c8a, 0x6da42045, 0x600fef22, 0x41dace6b, 0x64f9bdd4, 0x5d42d4fe,
      0x76b1516d, 0x6fc9a717, 0x70ac4fb6, 0x00194ef6, 0x22b644e2, 0x1f7916d5, 0x47581be2, 0x2710a123},
     {0x6284e867, 0x018d3afe, 0x5df99ef3, 0x4c1e467b, 0x566f6abc, 0x2994e427, 0x538a6d42, 0x5d7bf2cf,
@@ -40,9 +40,13 @@ __constant__ uint32_t RC_FULL[8][16] = {
     {0x7c93e00e, 0x561fbb4d, 0x1178907b, 0x02737406, 0x32fb24f1, 0x6323b60a, 0x6ab12418, 0x42c99cea,
      0x155a0b97, 0x53d1c6aa, 0x2bd20347, 0x279b3d73, 0x4f5f3c70, 0x0245af6c, 0x238359d3, 0x49966a59}};
 
-__constant__ uint32_t RC_PARTIAL[14] = {0x7f7ec4bf, 0x0421926f, 0x5198e669, 0x34db3148, 0x4368bafd,
+// what the linear layer of the LAST first-half full round adds: only lane 0 gets a constant (the first partial one)
+__constant__ __attribute__((aligned(64))) uint32_t RC_FIRST_PARTIAL[16] = {0x7f7ec4bf};
+
+__constant__ __attribute__((aligned(64))) uint32_t RC_PARTIAL[16] = {  // 14 constants + 2 words of padding (block loads)
+   0x7f7ec4bf, 0x0421926f, 0x5198e669, 0x34db3148, 0x4368bafd,
                                         0x66685c7f, 0x78d3249a, 0x60187881, 0x76dad67a, 0x0690b437,
-                                        0x1ea95311, 0x40e5369a, 0x38f103fc, 0x1d226a21};
+                                        0x1ea95311, 0x40e5369a, 0x38f103fc, 0x1d226a21, 0, 0};
 
 // ---- straightforward canonical implementation (readable restatement; baseline of tools/perm_lab.hip)
 __device__ __forceinline__ uint32_t pow5_ref(uint32_t x) {
@@ -210,19 +214,33 @@ __device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, uint32_t v2, 
     }
 }
 
+// 16 wave-uniform constants as ONE block (s_load_dwordx16 into SGPRs).  Per-constant scalar loads are consumed a few
+// instructions after their issue and stall the wave for the whole scalar-cache latency each time.
+__device__ __forceinline__ void load_rc16(const uint32_t* p, uint32_t* dst) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { uint4 t4 = p4[q]; dst[4 * q] = t4.x; dst[4 * q + 1] = t4.y; dst[4 * q + 2] = t4.z; dst[4 * q + 3] = t4.w; }
+}
+
 __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     uint64_t V[16];
     const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
     uint32_t v2;  // the constant 2 in a VGPR (multiplier of the SGPR-resident round constants)
     asm volatile("v_mov_b32 %0, 2" : "=v"(v2));
     // s: canonical input.  After every full-round linear layer: s[i] = canon(fold2(V[i])) in C.
-    mds16_2x(k2, k4, v2, s, V, RC_FULL[0], 16);
+    {
+        uint32_t rc0[16];
+        load_rc16(RC_FULL[0], rc0);
+        mds16_2x(k2, k4, v2, s, V, rc0, 16);
+    }
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
+        // the next round's constants, issued ahead of the S-box layer that hides the load
+        uint32_t rcn[16];
+        load_rc16(r < 3 ? RC_FULL[r + 1] : RC_FIRST_PARTIAL, rcn);
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));       // fold <= P + 161 <= 2P
-        if (r < 3) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
-        else mds16_2x(k2, k4, v2, s, V, RC_PARTIAL, 1);                                  // only lane 0 gets a constant
+        mds16_2x(k2, k4, v2, s, V, rcn, 16);  // r == 3: RC_FIRST_PARTIAL, zero for lanes 1..15 (keeps the loop uniform)
     }
     // partial rounds: lanes 1..15 stay lazily folded (< 2^31 + 2^18), lane 0 goes through the S-box
 #pragma unroll
@@ -234,8 +252,16 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
     RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
 #undef RSV_KD
-#pragma unroll 1
+    // Unrolled, with the 14 partial-round constants loaded as one block: rcp[r + 1] is then an SGPR operand; a scalar
+    // load per round would be consumed ~7 instructions after its issue and stall the wave for its whole latency,
+    // 13 times per permutation.  rc4: the constants of the full round after the partial ones ride on the last partial
+    // round's accumulators; loaded one round ahead.
+    uint32_t rcp[16], rc4[16];
+    load_rc16(RC_PARTIAL, rcp);
+#pragma unroll
     for (int r = 0; r < 14; r++) {
+        if (r == 12) load_rc16(RC_FULL[4], rc4);
+        const uint32_t rc_next = rcp[r < 13 ? r + 1 : 13];
         uint32_t u0 = pow5(canon(s[0]));                                     // s[0] <= 2P
         // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
         uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
@@ -245,18 +271,20 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
         // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50
         uint64_t v0 = mad64(u0, k6, sum2);
         if (r < 13) {
-            s[0] = fold2(mad64u(RC_PARTIAL[r + 1], v2, v0));
+            s[0] = fold2(mad64u(rc_next, v2, v0));
 #pragma unroll
             for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
         } else {
             // the constants of the next full round ride on the accumulators
-            s[0] = fold2(mad64u(RC_FULL[4][0], v2, v0));
+            s[0] = fold2(mad64u(rc4[0], v2, v0));
 #pragma unroll
-            for (int i = 1; i < 16; i++) s[i] = fold2(mad64u(RC_FULL[4][i], v2, mad64(s[i], kd[i], sum2)));
+            for (int i = 1; i < 16; i++) s[i] = fold2(mad64u(rc4[i], v2, mad64(s[i], kd[i], sum2)));
         }
     }
 #pragma unroll 1
     for (int r = 4; r < 8; r++) {
+        uint32_t rcn[16];
+        load_rc16(RC_FULL[r < 7 ? r + 1 : 7], rcn);
         if (r == 4) {
 #pragma unroll
             for (int i = 0; i < 16; i++) s[i] = pow5(canon(s[i]));           // s[i] < 2^31 + 2^19 <= 2P
@@ -264,7 +292,7 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
 #pragma unroll
             for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));
         }
-        if (r < 7) mds16_2x(k2, k4, v2, s, V, RC_FULL[r + 1], 16);
+        if (r < 7) mds16_2x(k2, k4, v2, s, V, rcn, 16);
         else mds16_2x(k2, k4, v2, s, V, nullptr, 0);
     }
     // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
