@@ -1,5 +1,7 @@
 """GPU parity tests: every C-ABI entry point of librsv_hip.so against the CPU oracle on the same
 inputs (bit-exact: all arithmetic is integer), and against the committed golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 
@@ -579,3 +581,59 @@ def test_reject_fixtures_behind_the_proof_of_work(rsv):
     oacc, oreason = ob.verify_batch(batch, inputs)
     assert acc.tolist() == oacc.tolist() == [0, 1, 0] * 3
     assert reason.tolist() == oreason.tolist() == [4, 0, 5] * 3
+
+
+def _debug_lib():
+    import ctypes
+    import torch  # noqa: F401  (one HIP runtime per process: torch's)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recursive-stwo_amd", "csrc", "librsv_hip_count.so")
+    if not os.path.exists(path):
+        pytest.skip("diagnostic build missing (make -C recursive-stwo_amd/csrc count)")
+    lib = ctypes.CDLL(path)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    lib.rsv_debug_plan.restype = ctypes.c_int
+    lib.rsv_debug_plan.argtypes = [ctypes.c_uint32] * 5 + [u32p, ctypes.c_int] + [u32p] * 7
+    return lib, u32p
+
+
+def _run_plan(lib, u32p, raw, nq, M, A, B, serial):
+    n = raw.shape[0]
+    G = max(nq, 4)
+    outs = [np.zeros((n, nq), np.uint32), np.zeros((n, nq), np.uint32), np.zeros((n, (M + 1) * G), np.uint32),
+            np.zeros((n, 2 * G), np.uint32), np.zeros((n, 32), np.uint32), np.zeros((n, 32), np.uint32), np.zeros((n, 8), np.uint32)]
+    rc = lib.rsv_debug_plan(n, nq, M, A, B, raw.ctypes.data_as(u32p), 1 if serial else 0, *[o.ctypes.data_as(u32p) for o in outs])
+    assert rc == 0, rc
+    return outs
+
+
+def test_plan_kernels_agree_on_synthetic_query_sets():
+    """k_plan_par (bitmask popcounts, one lane per query) against k_plan (serial walk) on shapes no fixture has:
+    n_queries 1..128, M up to 30, random / clustered / consecutive positions.  Every table must be identical; with
+    duplicate positions (rejected anyway) the sorted list and the DUP flag must agree and every index stay in range."""
+    lib, u32p = _debug_lib()
+    rng = np.random.default_rng(77)
+    shapes = [(1, 5, 4, 3), (4, 6, 5, 5), (5, 9, 8, 7), (8, 26, 25, 24), (10, 24, 23, 23), (11, 30, 29, 28), (16, 22, 21, 20),
+              (27, 23, 22, 21), (33, 12, 11, 10), (64, 20, 19, 19), (65, 18, 17, 16), (80, 24, 23, 22), (100, 16, 15, 14),
+              (127, 30, 28, 29), (128, 9, 8, 7), (128, 30, 29, 28)]
+    for nq, M, A, B in shapes:
+        n = 48
+        raw = rng.integers(0, 1 << 32, (n, nq), dtype=np.uint64).astype(np.uint32)
+        raw[8:16] &= np.uint32((1 << max(M - 3, 1)) - 1) | np.uint32(0xFFFFFFFF << M & 0xFFFFFFFF)   # clustered in the low part
+        raw[16:24] = (rng.integers(0, 1 << M, (8, 1), dtype=np.uint64) + np.arange(nq)[None, :]).astype(np.uint32)  # consecutive
+        raw[24:32] = (raw[24:32] >> np.uint32(32 - min(M, 8))) << np.uint32(max(M - 8, 0))    # few distinct high prefixes
+        raw[32:40, nq // 2:] = raw[32:40, :nq - nq // 2]                                        # duplicates
+        ser = _run_plan(lib, u32p, raw, nq, M, A, B, True)
+        par = _run_plan(lib, u32p, raw, nq, M, A, B, False)
+        qs = ser[0]
+        dup = np.array([len(set(r.tolist())) < nq for r in (raw & np.uint32((1 << M) - 1))])
+        assert np.array_equal(ser[0], par[0]), (nq, M)                       # sorted positions
+        assert np.array_equal(ser[6][:, 0] & 32, par[6][:, 0] & 32)          # R_DUP_QUERY bit
+        assert np.array_equal((ser[6][:, 0] & 32) != 0, dup)
+        ok = ~dup
+        for k, name in enumerate(["q", "qperm", "ent", "fl", "lvl", "wf", "misc"]):
+            assert np.array_equal(ser[k][ok], par[k][ok]), (name, nq, M, A, B)
+        # in range even for the rejected ones
+        G = max(nq, 4)
+        ent = par[2].reshape(n, M + 1, G)[:, 1:, :nq]
+        sib = (ent >> 16) & 0xFF
+        assert ((sib == 0xFF) | (sib < nq)).all() and ((ent & 0xFF) < nq).all()
