@@ -199,7 +199,8 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
  * RSV_HOST_CHUNK_MB (env, default 256) MB are gathered into pinned staging memory by worker threads
  * (RSV_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
  * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  lens[i] must be a
- * multiple of 4 (every proof of this type is), else RSV_E_SIZE. */
+ * multiple of 4 (every proof of this type is), else RSV_E_SIZE.  A buffer longer than 32 MB (a well-formed proof is
+ * below 8 MB) is not uploaded and gets RSV_R_PARSE. */
 int rsv_verify_batch_host(rsv_ctx* ctx, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
                           const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
                           uint8_t* reason);

@@ -495,6 +495,10 @@ def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
     # misaligned length is an API error
     with pytest.raises(rsv.RsvError):
         ctx.verify_batch_host([b"\x00" * 6])
+    # an absurdly long buffer is not uploaded: RSV_R_PARSE, and its neighbours are unaffected
+    big = np.zeros(40 << 20, np.uint8)
+    acc2, reason2 = ctx.verify_batch_host([proofs[0], big, proofs[0]])
+    assert acc2.tolist() == [1, 0, 1] and reason2.tolist() == [0, 1, 0]
     assert ctx.verify_batch_host([])[0].size == 0
     ctx.close()
 
