@@ -4,14 +4,22 @@
 A "step" is one pass of the verify pipeline over one synthetic batch that is already resident in HBM:
 BASELINE configs[2], 65 536 proofs built round-robin from the reference's four standard-config fixtures
 (recursive_proof_16_15, level3-1, level6-1, level7-1) with the seeded tamper rule of SURVEY §8d
-(proof i with i % 17 == 5 gets one flipped bit).  With --gpus N every rank verifies its own
-65 536-proof shard of an N x 65 536 batch (weak scaling) and the accept bitmaps are exchanged with one
-all_gather per step (RCCL).  Rank 0 prints ONE JSON line.
+(proof i with i % 17 == 5 gets one flipped bit), verified under the reference's `standard_config`
+(examples/multi-proofs/src/main.rs:173-176).
 
-Launch: `python bench.py` (N=1) or
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+Multi-GPU (`--gpus N`): one process per GPU.  Rank r verifies the contiguous shard r of the job and the ranks
+exchange their accept bitmaps with one all-gather + one all-reduce of the count per step over RCCL
+(recursive-stwo_amd/sharding.py: ShardedVerifier.step — the same function the tests cover).
+  * default: every rank gets `--proofs` proofs (65 536)                      -> "scaling": "weak"
+  * `--total-proofs T` (BASELINE configs[3]: 1 048 576): the job is T proofs, split over the ranks -> "strong"
+Rank 0 prints ONE JSON line.
+
+Launch: `python bench.py [--gpus N]` — for N > 1 this process only starts N rank processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, as children, before
+anything touches a GPU) and waits for them; the explicit torchrun form the driver uses works as well.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -49,8 +57,28 @@ def read_fixture(name):
         return f.read()
 
 
+def fixture_configs(rsv, fixtures):
+    """The PcsConfig literal the reference verifies each fixture under (tests/golden/manifest.json cites the source
+    line of every one: examples/multi-proofs/src/main.rs:173-295)."""
+    with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+        man = {e["file"]: e for e in json.load(f)["proofs"]}
+    return [rsv.PcsConfig(man[f]["pow_bits"], man[f]["log_blowup_factor"], man[f]["log_last_layer_degree_bound"],
+                          man[f]["n_queries"]) for f in fixtures]
+
+
+def kernel_sources_sha():
+    """Identity of the kernels a profile was taken on (there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "recursive-stwo_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip", ".inc")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
-    """Returns (d_blob uint8, d_offsets int64[n+1], lengths, tamper byte offsets) for global proof
+    """Returns (d_blob uint8, d_offsets int64[n+1], lengths, tamper indices, fixture index per proof) for global proof
     indices [first_index, first_index + n_proofs)."""
     proofs = [read_fixture(f) for f in fixtures]
     lens = np.array([len(p) for p in proofs], dtype=np.int64)
@@ -59,7 +87,7 @@ def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
     offsets = np.zeros(n_proofs + 1, dtype=np.int64)
     np.cumsum(plen, out=offsets[1:])
     total = int(offsets[-1])
-    # one period (4 proofs, aligned to the round-robin phase) tiled across the batch, built in HBM
+    # one period (aligned to the round-robin phase) tiled across the batch, built in HBM
     phase = int(first_index % len(proofs))
     order = [(phase + k) % len(proofs) for k in range(len(proofs))]
     period = np.frombuffer(b"".join(proofs[k] for k in order), dtype=np.uint8)
@@ -74,16 +102,19 @@ def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
         d_pos = torch.from_numpy(pos).to(dev)
         d_blob[d_pos] = d_blob[d_pos] ^ 1
     d_offsets = torch.from_numpy(offsets).to(dev)
-    return d_blob, d_offsets, plen, np.array(tam, dtype=np.int64)
+    return d_blob, d_offsets, plen, np.array(tam, dtype=np.int64), idx
 
 
-def cpu_baseline(blob_host, offsets, n_sample, fixtures=None):
+def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
     """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores."""
+    import ctypes
     from tests import oracle_binding as ob
     threads = max(1, min(os.cpu_count() or 1, 16))
     n_sample = min(n_sample, len(offsets) - 1)
     bounds = np.linspace(0, n_sample, threads + 1).astype(int)
     pi = ob.make_inputs(ob.STANDARD_INPUTS)
+    arr = (ob.PcsConfig * len(cfg_rows))(*[ob.PcsConfig(*r) for r in cfg_rows])
+    of = np.ascontiguousarray(cfg_of[:n_sample], dtype=np.uint8)
 
     def work(t):
         lo, hi = bounds[t], bounds[t + 1]
@@ -91,7 +122,8 @@ def cpu_baseline(blob_host, offsets, n_sample, fixtures=None):
             return 0
         offs = np.ascontiguousarray(offsets[lo:hi + 1], dtype=np.uint64)
         acc = np.zeros(hi - lo, np.uint8)
-        rc = ob.lib.rsvo_verify_batch(blob_host.ctypes.data_as(ob._u8p), offs.ctypes.data_as(ob._u64p), hi - lo, None,
+        cs = ob.CfgSet(ctypes.cast(arr, ctypes.POINTER(ob.PcsConfig)), len(cfg_rows), of[lo:hi].ctypes.data)
+        rc = ob.lib.rsvo_verify_batch(blob_host.ctypes.data_as(ob._u8p), offs.ctypes.data_as(ob._u64p), hi - lo, ctypes.byref(cs),
                                       pi, 3, acc.ctypes.data_as(ob._u8p), None)
         assert rc == 0
         return int(acc.sum())
@@ -108,12 +140,30 @@ def cpu_baseline(blob_host, offsets, n_sample, fixtures=None):
             "perms_per_proof": (sum(perms) / len(perms)) if perms else None}
 
 
+# Instruction-cost ceiling of the permutation on one MI355X (costs measured with tools/valu_lab.hip at
+# 4 waves/SIMD): per 64 permutations (one wave-level call of poseidon2()) the kernel issues ~1 660 slow-class
+# wave-instructions (v_mad_u64_u32 / v_lshl_add_u64, ~4.5 cycles each) and ~2 800 fast-class ones (~2.5 cycles);
+# 1 024 SIMDs at the sustained 2.37 GHz the Merkle kernels hold.  See tools/perm_ceiling.py for the census that
+# produces the two instruction counts from the shipped code object.
+PERM_SLOW_INSTS, PERM_FAST_INSTS = 1660, 2800
+PERM_SLOW_CYCLES, PERM_FAST_CYCLES = 4.5, 2.5
+SIMDS, SUSTAINED_GHZ = 1024, 2.37
+
+
+def perm_ceiling_per_s():
+    cycles_per_wave_call = PERM_SLOW_INSTS * PERM_SLOW_CYCLES + PERM_FAST_INSTS * PERM_FAST_CYCLES
+    return SIMDS * SUSTAINED_GHZ * 1e9 / cycles_per_wave_call * 64.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--proofs", type=int, default=65536, help="proofs per GPU per step")
+    ap.add_argument("--proofs", type=int, default=65536, help="proofs per GPU per step (weak scaling)")
+    ap.add_argument("--total-proofs", type=int, default=0,
+                    help="proofs of the WHOLE job per step, split contiguously over the ranks (strong scaling; "
+                         "BASELINE configs[3] = 1048576)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="oracle sample size (0 = skip, -1 = auto)")
     ap.add_argument("--perm-log2", type=int, default=24, help="Poseidon2 microbench size (log2 states, 0 = skip)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="standard")
@@ -122,44 +172,44 @@ def main():
                          "verifying pass; needs a uniform-shape workload")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # ---- plain `python bench.py --gpus N`: start the N ranks as child processes and wait.  This process loads neither
+    # torch nor the HIP library (sharding.py is imported by path; it needs only the standard library and numpy).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("rsv_sharding_launcher", os.path.join(ROOT, "recursive-stwo_amd", "sharding.py"))
+        launcher = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launcher)
+        sys.exit(launcher.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     import rsvload
     rsv = rsvload.load_package()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
-    if not torch.cuda.is_available() or rsv.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    from recursive_stwo_amd import sharding
+    import torch
+    import torch.distributed as dist
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     # Rehearsal mode for a one-GPU box: RSV_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges the
     # bitmaps over gloo (RCCL refuses two ranks on one device).  The driver's real runs use nccl (= RCCL).
     rehearsal = os.environ.get("RSV_BENCH_REHEARSAL") == "1"
-    dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
+    if torch.cuda.device_count() < (1 if rehearsal else world_env):
+        raise SystemExit("bench.py needs one HIP device per rank: the product has no CPU fallback")
+    rank, world, dev_index = sharding.init_rank(torch, dist, rehearsal)
+    if rsv.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
     dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
 
-    n = args.proofs
-    first = rank * n
+    strong = args.total_proofs > 0
+    n_total = args.total_proofs if strong else world * args.proofs
+    first, last = sharding.shard_range(n_total, rank, world)
+    n = last - first
     fixtures = WORKLOADS[args.workload]
-    d_blob, d_offsets, plen, tam = build_batch_on_device(torch, dev, n, first, fixtures)
+    d_blob, d_offsets, plen, tam, fix_idx = build_batch_on_device(torch, dev, n, first, fixtures)
     total_bytes = int(plen.sum())
-    d_accept = torch.zeros(n, dtype=torch.uint8, device=dev)
-    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
-    n_words = (n + 31) // 32
-    d_bitmap = torch.zeros(n_words, dtype=torch.int32, device=dev)
-    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    d_all = torch.zeros(world * n_words, dtype=torch.int32, device=dev) if world > 1 else None
-    ctx = rsv.Context(dev_index)
+    sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch)
+    # the configuration of every proof: the reference's literal for the fixture it was copied from
+    fcfg = fixture_configs(rsv, fixtures)
+    cfg = sv.ctx.prepare_cfg([fcfg[k] for k in fix_idx], n) if len({rsv._cfg_key(c) for c in fcfg}) > 1 else rsv.PreparedCfg([fcfg[0]])
     hints = None
     if args.emit_paths:
         hdr = np.frombuffer(read_fixture(fixtures[0])[:64], dtype=np.uint32)
@@ -175,23 +225,10 @@ def main():
                      d_fri_folded=torch.zeros((n, 3, p_nq, 4), dtype=torch.int32, device=dev))
 
     def step():
-        if hints:
-            ctx.verify_hints(d_blob, d_offsets, n, d_accept, d_reason, **hints)
-        else:
-            ctx.verify_batch(d_blob, d_offsets, n, d_accept, d_reason)
-        ctx.accept_bitmap(d_accept, n, d_bitmap, d_count)
-        if world > 1:
-            ctx.synchronize()  # bitmap produced on the verifier's stream, exchanged on torch's
-            if rehearsal:
-                h_all = torch.zeros(world * n_words, dtype=torch.int32)
-                dist.all_gather_into_tensor(h_all, d_bitmap.cpu())
-                d_all.copy_(h_all)
-            else:
-                dist.all_gather_into_tensor(d_all, d_bitmap)
+        sv.step(d_blob, d_offsets, cfg, hints=hints)
 
     def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        sv.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -203,9 +240,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP-event stage times of this step (reads events already recorded on the stream)
+        # HIP-event stage times of this step (reads events already recorded on the verifier's streams)
         if rank == 0:
-            for k, v in ctx.last_stage_times().items():
+            for k, v in sv.ctx.last_stage_times().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     fence()
     dt = time.perf_counter() - t0
@@ -215,55 +252,59 @@ def main():
         dt = float(tmax.item())
 
     # correctness of what was just timed: every untampered proof accepted, every tampered one rejected
-    acc = d_accept.cpu().numpy()
+    acc = sv.d_accept[:n].cpu().numpy()
     want = np.ones(n, np.uint8)
     want[tam] = 0
     if not np.array_equal(acc, want):
         raise SystemExit(f"rank {rank}: verdict mismatch: {int((acc != want).sum())} proofs differ from the expected accept map")
-    if int(d_count.item()) != int(want.sum()):
-        raise SystemExit("accept popcount mismatch")
-    if world > 1:
-        # every rank now holds the whole job's accept bitmap: check it against the global tamper rule
-        allbits = np.unpackbits(d_all.cpu().numpy().view(np.uint8), bitorder="little").reshape(world, -1)[:, :n]
-        for r in range(world):
-            exp = ((np.arange(n) + r * n) % 17 != 5).astype(np.uint8)
-            if not np.array_equal(allbits[r], exp):
-                raise SystemExit(f"rank {rank}: gathered bitmap of rank {r} differs from the expected accept map")
+    # every rank now holds the whole job's accept bitmap and count: check them against the global tamper rule
+    job = sv.exchange.assemble()
+    job_want = (np.arange(n_total) % 17 != 5).astype(np.uint8)
+    if not np.array_equal(job, job_want):
+        raise SystemExit(f"rank {rank}: gathered bitmap differs from the expected accept map of the job")
+    if sv.exchange.total_accepted() != int(job_want.sum()):
+        raise SystemExit("accept count (all-reduce) mismatch")
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
+    ctx = sv.ctx
     ms_per_step = dt / args.steps * 1e3
-    value = world * n * args.steps / dt
+    value = n_total * args.steps / dt
     stage_avg = {k: v / args.steps for k, v in stage_sum.items()}
     dom = max((k for k in stage_avg if k.endswith("merkle")), key=lambda k: stage_avg[k])
     dom_ms = stage_avg[dom]
     algo_bytes = total_bytes + n  # proof bytes read once + 1 accept byte per proof
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # measured HBM traffic of the dominant kernel from profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # passes of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled to this batch size
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC bytes measured by tools/profile.sh on THESE kernel sources, else null.
+    traffic, traffic_note = None, "traffic: no PMC profile of these kernel sources under profiles/ (tools/profile.sh writes pmc_latest.json)"
     try:
-        import csv
-        with open(os.path.join(ROOT, "profiles", "r1_final_pmc_summary.csv")) as f:
-            rows = list(csv.reader(line for line in f if not line.startswith("#")))
-        hdr = rows[0]
-        for r in rows[1:]:
-            if dom in r[0]:
-                traffic = float(r[hdr.index("hbm_bytes_corrected")]) * (n / 65536.0)
-    except Exception:
-        traffic = None
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            prof = json.load(f)
+        if prof.get("kernel_sources_sha") != kernel_sources_sha():
+            traffic_note = (f"traffic: profiles/pmc_latest.json was measured on other kernel sources "
+                            f"({prof.get('kernel_sources_sha')}), not reported")
+        elif args.workload != "standard" or n != prof.get("proofs"):
+            traffic_note = "traffic: profiles/pmc_latest.json holds the default workload only, not reported for this one"
+        else:
+            traffic = float(prof["kernels"]["k_" + dom]["hbm_bytes_corrected"])
+            traffic_note = (f"traffic: HBM bytes of k_{dom} per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            f"command on these kernel sources ({prof['tag']}), FETCH_SIZE doubled per MI355X_MICROARCH.md")
+    except (OSError, KeyError, ValueError):
+        pass
+    pipeline_gbps = algo_bytes / (ms_per_step * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms,
-                "pipeline_ms": ms_per_step, "pipeline_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+                "pipeline_ms": ms_per_step, "pipeline_GBps": pipeline_gbps, "pipeline_frac": pipeline_gbps / HBM_PEAK_GBPS,
                 "stage_ms": stage_avg,
-                "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY \u00a78d); see valu. "
-                        "kernel_ms / stage_ms are HIP-event times on the verifier's streams; side-stream stages "
-                        "overlap the main stream, so stage_ms do not add up to pipeline_ms (wall time per step). "
-                        "traffic: PMC bytes of the dominant kernel from profiles/r1_final_pmc_summary.csv"}
+                "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY §8d); see valu. "
+                        "frac charges the whole proof to the dominant kernel (SURVEY §8d's numerator); pipeline_frac "
+                        "is the same bytes over the wall time of a step on rank 0.  kernel_ms / stage_ms are HIP-event "
+                        "times on the verifier's streams; side-stream stages overlap the main stream, so stage_ms do not "
+                        "add up to pipeline_ms.  " + traffic_note}
 
     # Poseidon2 microbench (second metric of BASELINE.json): 2^k states resident in HBM, 128 B per permutation
     valu = None
@@ -282,8 +323,12 @@ def main():
         ctx.synchronize()
         pdt = (time.perf_counter() - t1) / reps
         perms_per_s = m / pdt
+        ceil = perm_ceiling_per_s()
         valu = {"poseidon2_perms_per_s": perms_per_s, "perm_GBps": m * 128 / pdt / 1e9,
-                "perm_hbm_frac": m * 128 / pdt / 1e9 / HBM_PEAK_GBPS, "states": m}
+                "perm_hbm_frac": m * 128 / pdt / 1e9 / HBM_PEAK_GBPS, "states": m,
+                "ceiling_perms_per_s": ceil, "frac_of_ceiling": perms_per_s / ceil,
+                "ceiling_model": f"{PERM_SLOW_INSTS} x {PERM_SLOW_CYCLES} + {PERM_FAST_INSTS} x {PERM_FAST_CYCLES} cycles per "
+                                 f"64 permutations, {SIMDS} SIMDs at {SUSTAINED_GHZ} GHz (DESIGN §4)"}
         del d_in, d_out
 
     cpu = None
@@ -295,24 +340,34 @@ def main():
         n_s = min(sample, n)
         end = int(d_offsets[n_s].item())
         blob_host = d_blob[:end].cpu().numpy()
-        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s, fixtures)
+        rows = [rsv._cfg_key(c) for c in fcfg]
+        table = sorted(set(rows))
+        of = np.array([table.index(rows[k]) for k in fix_idx[:n_s]], np.uint8)
+        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s, table, of, fixtures)
         if valu is not None and cpu.get("perms_per_proof"):
-            # useful permutations (the oracle's batched-walk count) the pipeline retires per second, against the bare
-            # permutation kernel measured above: the efficiency figure of this VALU-bound path
-            valu["pipeline_useful_perms_per_s"] = cpu["perms_per_proof"] * value
-            valu["pipeline_frac_of_perm_kernel"] = valu["pipeline_useful_perms_per_s"] / (world * valu["poseidon2_perms_per_s"])
+            # useful permutations (the oracle's batched-walk count) the whole pipeline retires per second and GPU, against
+            # the instruction-cost ceiling of the bare permutation: the efficiency figure of this VALU-bound path
+            valu["pipeline_useful_perms_per_s_per_gpu"] = cpu["perms_per_proof"] * value / world
+            valu["pipeline_frac_of_ceiling"] = valu["pipeline_useful_perms_per_s_per_gpu"] / valu["ceiling_perms_per_s"]
 
+    if strong:
+        wl = (f"{'BASELINE configs[3]' if args.workload == 'standard' else args.workload}: {n_total} proofs per step split "
+              f"contiguously over {world} GPU(s), round-robin over {fixtures}")
+    else:
+        wl = (f"{'BASELINE configs[2]' if args.workload == 'standard' else args.workload}: {n} proofs/GPU round-robin over {fixtures}")
     line = {
         "metric": "recursive proofs verified/sec", "value": value, "unit": "proofs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31 modular integers)", "data": "synthetic",
-        "config": {"workload": f"{'BASELINE configs[2]' if args.workload == 'standard' else args.workload}: {n} proofs/GPU round-robin over {fixtures}, i%17==5 tampered "
-                               f"(SURVEY §8d), full verify; bit-exact accept map checked",
-                   "proofs_per_gpu": n, "bytes_per_gpu": total_bytes, "parallelism": f"shard{world}"},
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32 (M31 modular integers)", "data": "synthetic",
+        "config": {"workload": wl + ", i%17==5 tampered (SURVEY §8d), full verify under the reference's PcsConfig literals; "
+                                    "bit-exact accept map of the whole job checked on every rank",
+                   "proofs_per_step": n_total, "proofs_rank0": n, "bytes_rank0": total_bytes, "parallelism": f"shard{world}",
+                   "exchange": "all_gather(accept bitmap) + all_reduce(count) per step, " + ("gloo (rehearsal)" if rehearsal else
+                               ("nccl/RCCL" if world > 1 else "none (1 rank)"))},
         "roofline": roofline, "cpu_baseline": cpu, "valu": valu,
     }
-    print(json.dumps(line))
-    if world > 1:
+    print(json.dumps(line), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

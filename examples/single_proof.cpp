@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     const Inputs inputs = {{1, QM31{1, 0, 0, 0}}};
     try {
         // FiatShamirHints / DecommitHints / FirstLayerHints / InnerLayersHints (:33-41)
-        Hints hints = Hints::compute(proof, inputs);
+        Hints hints = Hints::compute(proof, config, inputs);
         size_t paths = 0;
         for (auto& tree : hints.decommit) for (auto& p : tree) { p.verify(); paths++; }
         for (auto& p : hints.first_layer_merkle_proofs) { p.verify(); paths++; }

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RSV_M31_P 0x7fffffffu
-#define RSV_ABI_VERSION 1
+#define RSV_ABI_VERSION 2
 
 typedef enum rsv_status {
     RSV_OK = 0,
@@ -75,6 +75,22 @@ typedef struct rsv_pcs_config {
     uint32_t n_queries;
 } rsv_pcs_config;
 
+/* The configuration(s) the caller expects — REQUIRED by every entry point that produces a verdict.  The reference
+ * never takes the configuration from the proof: FiatShamirHints::new(&proof, config, ..)
+ * (components/hints/src/fiat_shamir.rs:69-74), examples/multi-proofs/src/main.rs:173-196 pass it in; a verifier that
+ * trusted the serialized words would let a forger choose pow_bits = 0, n_queries = 1.  Proof i must carry exactly
+ * cfgs[cfg_of ? cfg_of[i] : 0] in its header, else it is rejected with RSV_R_PARSE.
+ *   cfgs    n_cfgs (1..RSV_MAX_CFGS) configurations, HOST memory
+ *   cfg_of  one index per proof (a mixed batch, e.g. the 6 configurations of the multi-proofs chain) or NULL;
+ *           same residency as the blob: device memory for the _dev entry points, host memory otherwise.
+ *           An index >= n_cfgs rejects the proof (RSV_R_PARSE). */
+#define RSV_MAX_CFGS 16
+typedef struct rsv_cfg_set {
+    const rsv_pcs_config* cfgs;
+    uint32_t n_cfgs;
+    const uint8_t* cfg_of;
+} rsv_cfg_set;
+
 /* One public input `(wire index, QM31 value)` as passed to
  * FiatShamirResults::compute(.., inputs) (components/recursive/fiat_shamir/src/lib.rs:31-36). */
 typedef struct rsv_public_input {
@@ -94,12 +110,23 @@ void rsv_ctx_destroy(rsv_ctx* ctx);
 int rsv_ctx_synchronize(rsv_ctx* ctx);
 /* The context's hipStream_t (as void*), so a caller can order its own work. */
 void* rsv_ctx_stream(rsv_ctx* ctx);
+/* Stream ordering with the caller's own HIP work (the context enqueues on private non-blocking streams):
+ *   rsv_ctx_wait_stream   everything enqueued so far on `hip_stream` (a hipStream_t; NULL = the legacy default stream)
+ *                         happens before whatever is enqueued on the context next — call it after producing the
+ *                         blob / offsets / output buffers with your own kernels or copies, before a _dev entry point;
+ *   rsv_stream_wait_ctx   the reverse: `hip_stream` waits for everything the context has enqueued so far.
+ * Neither blocks the host. */
+int rsv_ctx_wait_stream(rsv_ctx* ctx, void* hip_stream);
+int rsv_stream_wait_ctx(rsv_ctx* ctx, void* hip_stream);
 
 /* ---- a3: Poseidon2-M31 width-16 permutation -------------------------------
  * Replaces poseidon2_permute (primitives/poseidon31/src/implementation.rs:108-149).
  * n states of 16 words, state-major (state i at in16 + 16*i). */
 int rsv_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n, int device);
-int rsv_poseidon2_permute_dev(rsv_ctx* ctx, const uint32_t* d_in16, uint32_t* d_out16, size_t n);
+/* Device-resident form: enqueued on the context's stream, no host round trip.  Inputs >= P are still permuted
+ * (as canonical-mod-P garbage); if d_bad (device u32, may be NULL) is given it is set to 1 when any input word
+ * was not canonical and left untouched otherwise — the caller zeroes it and reads it when it synchronises. */
+int rsv_poseidon2_permute_dev(rsv_ctx* ctx, const uint32_t* d_in16, uint32_t* d_out16, size_t n, uint32_t* d_bad);
 
 /* ---- a4: Poseidon2HalfVar::permute with swap / rate / capacity ------------
  * Replaces Poseidon2HalfVar::permute(left,right,_,_,is_swap)
@@ -168,7 +195,9 @@ int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8,
  *   [32..40) channel digest after the proof-of-work mix
  *   [40..40+4*n_fri_alphas)  fri alphas
  *   then n_queries raw query words (before masking to M bits).
- * Returns RSV_E_CAP if cap (in words) is too small. */
+ * Returns RSV_E_CAP if cap (in words) is too small.
+ * PROBE, not a verdict: it replays the transcript under the configuration words serialized in the proof (no
+ * rsv_cfg_set), so word [0] == RSV_R_OK says nothing about the proof's security level. */
 int rsv_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap, int device);
 
 /* ---- full verify: a1-a13 --------------------------------------------------
@@ -177,13 +206,13 @@ int rsv_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap, 
  * (examples/single-proof/src/main.rs:48-82) on a batch of serialized
  * PlonkWithPoseidonProof<Poseidon31MerkleHasher> (bincode).
  *   blob     concatenated proof bytes; proof i = blob[offsets[i] .. offsets[i+1])
- *   cfg      NULL = trust the config serialized in each proof; else a proof
- *            whose embedded config differs is rejected with RSV_R_PARSE
+ *   cfg      REQUIRED (RSV_E_NULL otherwise): the configuration(s) the caller expects, see rsv_cfg_set; a proof
+ *            whose embedded configuration differs is rejected with RSV_R_PARSE
  *   pi,n_pi  public inputs shared by the whole batch
  *   accept   n bytes, 1 = verified        reason  n bytes of rsv_reason (may be NULL)
  */
 int rsv_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
-                     const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
+                     const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi,
                      uint8_t* accept, uint8_t* reason, int device);
 
 /* Same, inputs and outputs resident in HBM (d_ = device pointers); enqueued on
@@ -191,18 +220,18 @@ int rsv_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
  * aligned, d_blob 4-byte aligned and every offset a multiple of 4 (bincode
  * proofs of this type always have 4-byte-multiple lengths). */
 int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets,
-                         size_t n, const rsv_pcs_config* cfg, const rsv_public_input* pi,
+                         size_t n, const rsv_cfg_set* cfg, const rsv_public_input* pi,
                          size_t n_pi, uint8_t* d_accept, uint8_t* d_reason);
 
 /* Proofs that start in HOST memory, as the reference's callers hold them: one serialized buffer per proof
  * (bincode::serialize(&proof) -> Vec<u8>, examples/multi-proofs/src/main.rs:69-139).  Chunks of about
  * RSV_HOST_CHUNK_MB (env, default 256) MB are gathered into pinned staging memory by worker threads
  * (RSV_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
- * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  lens[i] must be a
- * multiple of 4 (every proof of this type is), else RSV_E_SIZE.  A buffer longer than 32 MB (a well-formed proof is
- * below 8 MB) is not uploaded and gets RSV_R_PARSE. */
+ * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  A buffer whose length is not a
+ * multiple of 4 (every proof of this type is a whole number of 32-bit words) or exceeds 32 MB (a well-formed proof is
+ * below 8 MB) is not uploaded and gets RSV_R_PARSE, like any other malformed proof. */
 int rsv_verify_batch_host(rsv_ctx* ctx, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
-                          const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
+                          const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
                           uint8_t* reason);
 
 /* ---- SURVEY 8f.1 (next row): per-query authentication paths -----------------
@@ -215,10 +244,11 @@ int rsv_verify_batch_host(rsv_ctx* ctx, const uint8_t* const* proofs, const uint
  *   d_pos  [n][4][n_queries]              position of the query at the tree's leaf level
  * Tree depths: max(lp, lq) + log_blowup for trees 0..2, M for tree 3.  accept/reason as in rsv_verify_batch_dev. */
 int rsv_trace_paths_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
-                        const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log,
+                        const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log,
                         uint32_t* d_sib, uint32_t* d_pos, uint8_t* d_accept, uint8_t* d_reason);
 /* Same on host buffers (copied to `device` and back). */
-int rsv_trace_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+int rsv_trace_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
+                    const rsv_public_input* pi, size_t n_pi,
                     uint32_t n_queries, uint32_t max_log, uint32_t* sib, uint32_t* pos, uint8_t* accept,
                     uint8_t* reason, int device);
 
@@ -231,9 +261,10 @@ int rsv_trace_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, cons
  *                                                   the hash of the sibling's children
  *   d_cols [n][1 + n_inner][n_queries][3][8]        c-th column level from the top: self value | sibling value */
 int rsv_fri_paths_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
-                      const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log, uint32_t n_inner,
+                      const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t n_queries, uint32_t max_log, uint32_t n_inner,
                       uint32_t* d_sib, uint32_t* d_cols, uint8_t* d_accept, uint8_t* d_reason);
-int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
+                  const rsv_public_input* pi, size_t n_pi,
                   uint32_t n_queries, uint32_t max_log, uint32_t n_inner, uint32_t* sib, uint32_t* cols, uint8_t* accept,
                   uint8_t* reason, int device);
 
@@ -264,14 +295,16 @@ typedef struct {
     uint32_t* d_fri_folded;
 } rsv_hints_out;
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
-                         const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,
+                         const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,
                          uint8_t* d_reason);
 /* Same with every pointer (blob, offsets, the outputs named in *out, accept, reason) in HOST memory: the library
  * stages them through HBM.  rsv_trace_paths, rsv_fri_paths and rsv_transcript_batch are special cases of it. */
-int rsv_verify_hints(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_public_input* pi, size_t n_pi,
+int rsv_verify_hints(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
+                     const rsv_public_input* pi, size_t n_pi,
                      const rsv_hints_out* out, uint8_t* accept, uint8_t* reason, int device);
 /* Host-buffer convenience for the transcript rows only (any mix of shapes): out is [n][RSV_TRANSCRIPT_WORDS]. */
-int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, uint32_t* out, int device);
+int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg, uint32_t* out,
+                         int device);
 
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).

@@ -1273,15 +1273,22 @@ done:
 #undef FAIL
 }
 
-int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_pcs_config* cfg,
+/* cfg is REQUIRED, as in the reference (FiatShamirHints::new(&proof, config, ..), components/hints/src/fiat_shamir.rs:69-74):
+ * proof i must carry cfgs[cfg_of ? cfg_of[i] : 0]; an index out of range rejects the proof (PARSE). */
+int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
                       const rsv_public_input* pi, size_t n_pi, uint8_t* accept, uint8_t* reason) {
     if (n && (!blob || !offsets || !accept)) return RSV_E_NULL;
     if (n_pi && !pi) return RSV_E_NULL;
+    if (!cfg || !cfg->cfgs) return RSV_E_NULL;
+    if (cfg->n_cfgs < 1 || cfg->n_cfgs > RSV_MAX_CFGS) return RSV_E_SIZE;
     for (size_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return RSV_E_SIZE;
     for (size_t i = 0; i < n_pi; i++) if (!canonical(pi[i].value, 4)) return RSV_E_RANGE;
     query_probe* scratch = calloc(1, sizeof *scratch);
     for (size_t i = 0; i < n; i++) {
-        uint8_t r = verify_one(blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), cfg, pi, n_pi, scratch);
+        const uint32_t ci = cfg->cfg_of ? cfg->cfg_of[i] : 0u;
+        uint8_t r = ci < cfg->n_cfgs
+                        ? verify_one(blob + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), &cfg->cfgs[ci], pi, n_pi, scratch)
+                        : (uint8_t)RSV_R_PARSE;
         accept[i] = r == RSV_R_OK;
         if (reason) reason[i] = r;
     }

@@ -35,7 +35,7 @@ int rsvo_grind_nonce(const uint8_t* proof, size_t len, uint64_t start, uint64_t 
                      uint64_t* nonce);
 int rsvo_transcript(const uint8_t* proof, size_t len, uint32_t* out, size_t cap);
 int rsvo_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
-                      const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
+                      const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi,
                       uint8_t* accept, uint8_t* reason);
 
 /* Extra probes used by the tests. */

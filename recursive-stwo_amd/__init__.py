@@ -48,6 +48,67 @@ class PcsConfig(ctypes.Structure):
                 ("log_last_layer_degree_bound", ctypes.c_uint32), ("n_queries", ctypes.c_uint32)]
 
 
+class CfgSet(ctypes.Structure):  # rsv_cfg_set
+    _fields_ = [("cfgs", ctypes.POINTER(PcsConfig)), ("n_cfgs", ctypes.c_uint32), ("cfg_of", ctypes.c_void_p)]
+
+
+MAX_CFGS = 16  # RSV_MAX_CFGS
+
+
+class PreparedCfg:
+    """An rsv_cfg_set ready to pass by reference: keeps the config array (and the cfg_of buffer: a numpy array for
+    the host entry points, a torch tensor in HBM for Context methods) alive."""
+
+    def __init__(self, cfgs: Sequence[PcsConfig], cfg_of=None):
+        if not 1 <= len(cfgs) <= MAX_CFGS:
+            raise ValueError(f"1..{MAX_CFGS} configurations")
+        self.arr = (PcsConfig * len(cfgs))(*[PcsConfig(c.pow_bits, c.log_blowup_factor, c.log_last_layer_degree_bound,
+                                                       c.n_queries) for c in cfgs])
+        self.cfg_of = cfg_of
+        if cfg_of is None:
+            ptr = None
+        elif isinstance(cfg_of, np.ndarray):
+            ptr = cfg_of.ctypes.data
+        else:
+            ptr = cfg_of.data_ptr()  # torch tensor
+        self.struct = CfgSet(ctypes.cast(self.arr, ctypes.POINTER(PcsConfig)), len(cfgs), ptr)
+
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+def _cfg_key(c) -> tuple:
+    return (int(c.pow_bits), int(c.log_blowup_factor), int(c.log_last_layer_degree_bound), int(c.n_queries))
+
+
+def prepare_cfg(cfg, n: int, to_device=None) -> PreparedCfg:
+    """cfg: one PcsConfig (every proof must carry it), or a sequence of n PcsConfig (one per proof; deduplicated into
+    at most MAX_CFGS distinct configurations + a per-proof index), or a PreparedCfg.  The configuration is REQUIRED:
+    the verifier never trusts the words serialized in a proof (include/rsv.h, rsv_cfg_set).
+    to_device: callable numpy uint8 array -> device tensor (Context methods), None for the host entry points."""
+    if isinstance(cfg, PreparedCfg):
+        return cfg
+    if cfg is None:
+        raise TypeError("a PcsConfig (or one per proof) is required: the verifier does not trust the configuration "
+                        "words serialized in a proof")
+    if isinstance(cfg, PcsConfig) or hasattr(cfg, "pow_bits"):
+        return PreparedCfg([cfg])
+    per_proof = list(cfg)
+    if len(per_proof) != n:
+        raise ValueError("one configuration per proof expected")
+    table, index = [], {}
+    cfg_of = np.zeros(n, np.uint8)
+    for i, c in enumerate(per_proof):
+        k = _cfg_key(c)
+        if k not in index:
+            index[k] = len(table)
+            table.append(c)
+        cfg_of[i] = index[k]
+    if len(table) <= 1:
+        return PreparedCfg(table or [PcsConfig(0, 0, 0, 0)])
+    return PreparedCfg(table, to_device(cfg_of) if to_device else cfg_of)
+
+
 class PublicInput(ctypes.Structure):
     _fields_ = [("idx", ctypes.c_uint32), ("value", ctypes.c_uint32 * 4)]
 
@@ -84,32 +145,34 @@ def _load() -> ctypes.CDLL:
         "rsv_ctx_synchronize": (ctypes.c_int, [vp]),
         "rsv_ctx_stream": (vp, [vp]),
         "rsv_poseidon2_permute": (ctypes.c_int, [_u32p, _u32p, sz, ctypes.c_int]),
-        "rsv_poseidon2_permute_dev": (ctypes.c_int, [vp, vp, vp, sz]),
+        "rsv_poseidon2_permute_dev": (ctypes.c_int, [vp, vp, vp, sz, vp]),
+        "rsv_ctx_wait_stream": (ctypes.c_int, [vp, vp]),
+        "rsv_stream_wait_ctx": (ctypes.c_int, [vp, vp]),
         "rsv_poseidon2_half_permute": (ctypes.c_int, [_u32p, _u32p, _u8p, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_merkle_hash_node": (ctypes.c_int, [_u32p, _u32p, _u32p, sz, _u32p, sz, ctypes.c_int]),
         "rsv_merkle_path_root": (ctypes.c_int, [_u32p, _u32p, _u32p, _u32p, ctypes.c_uint32, _u32p, sz, ctypes.c_int]),
         "rsv_transcript": (ctypes.c_int, [_u8p, sz, _u32p, sz, ctypes.c_int]),
-        "rsv_verify_batch": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput),
+        "rsv_verify_batch": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput),
                                             sz, _u8p, _u8p, ctypes.c_int]),
-        "rsv_verify_batch_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PcsConfig),
+        "rsv_verify_batch_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(CfgSet),
                                                 ctypes.POINTER(PublicInput), sz, vp, vp]),
         "rsv_accept_bitmap_dev": (ctypes.c_int, [vp, vp, sz, vp, vp]),
-        "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+        "rsv_trace_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                                ctypes.c_uint32, vp, vp, vp, vp]),
-        "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
+        "rsv_verify_hints_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), vp, vp]),
         "rsv_field_op": (ctypes.c_int, [ctypes.c_int, _u32p, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_domain_points": (ctypes.c_int, [ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_line_eval": (ctypes.c_int, [_u32p, ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
-        "rsv_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(PcsConfig),
+        "rsv_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(CfgSet),
                                                  ctypes.POINTER(PublicInput), sz, _u8p, _u8p]),
-        "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
+        "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
                                             ctypes.c_int]),
-        "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, _u32p, ctypes.c_int]),
-        "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+        "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), _u32p, ctypes.c_int]),
+        "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                              ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp]),
-        "rsv_fri_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32, ctypes.c_uint32,
+        "rsv_fri_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32, ctypes.c_uint32,
                                          ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
-        "rsv_trace_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+        "rsv_trace_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                            ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
         "rsv_last_stage_times": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                                 ctypes.c_int]),
@@ -123,7 +186,7 @@ def _load() -> ctypes.CDLL:
 
 lib = _load()
 EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_destroy", "rsv_ctx_synchronize",
-           "rsv_ctx_stream", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
+           "rsv_ctx_stream", "rsv_ctx_wait_stream", "rsv_stream_wait_ctx", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
@@ -284,20 +347,22 @@ def pack(proofs: Sequence[bytes]):
     return blob, offsets
 
 
-def verify_batch(proofs: Sequence[bytes], inputs=STANDARD_INPUTS, cfg: Optional[PcsConfig] = None, device: int = 0):
-    """Verify a batch of serialized proofs on the GPU.  Returns (accept uint8[n], reason uint8[n])."""
+def verify_batch(proofs: Sequence[bytes], cfg, inputs=STANDARD_INPUTS, device: int = 0):
+    """Verify a batch of serialized proofs on the GPU under the configuration(s) `cfg` (required: one PcsConfig, or
+    one per proof).  Returns (accept uint8[n], reason uint8[n])."""
     blob, offsets = pack(proofs)
     n = len(proofs)
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
     pi = make_inputs(inputs)
+    pc = prepare_cfg(cfg, n)
     _check(lib.rsv_verify_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n,
-                                ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+                                pc.ref(), pi, len(list(inputs)),
                                 accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_verify_batch")
     return accept, reason
 
 
-def trace_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, inputs=STANDARD_INPUTS, device: int = 0):
+def trace_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, inputs=STANDARD_INPUTS, device: int = 0):
     """per-query authentication paths of the four commitment trees, transcript query order.
     Returns (sib uint32[n,4,n_queries,max_log,8], pos uint32[n,4,n_queries], accept, reason)."""
     blob, offsets = pack(proofs)
@@ -307,23 +372,23 @@ def trace_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, inputs=ST
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
     pi = make_inputs(inputs)
-    _check(lib.rsv_trace_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, pi, len(list(inputs)),
+    _check(lib.rsv_trace_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), pi, len(list(inputs)),
                                n_queries, max_log, sib.ctypes.data_as(_u32p), pos.ctypes.data_as(_u32p),
                                accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_trace_paths")
     return sib, pos, accept, reason
 
 
-def transcript_batch(proofs: Sequence[bytes], device: int = 0) -> np.ndarray:
+def transcript_batch(proofs: Sequence[bytes], cfg, device: int = 0) -> np.ndarray:
     """FiatShamirHints of every proof of a batch (any mix of shapes): uint32[n, TRANSCRIPT_WORDS], layout in rsv.h."""
     blob, offsets = pack(proofs)
     n = len(proofs)
     out = np.zeros((n, TRANSCRIPT_WORDS), np.uint32)
-    _check(lib.rsv_transcript_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u32p),
+    _check(lib.rsv_transcript_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), out.ctypes.data_as(_u32p),
                                     device), "rsv_transcript_batch")
     return out
 
 
-def fri_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
+def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
     """per-query pair paths of the FRI trees.  Returns (sib uint32[n,1+n_inner,nq,max_log,8],
     cols uint32[n,1+n_inner,nq,3,8], accept, reason)."""
     blob, offsets = pack(proofs)
@@ -333,7 +398,7 @@ def fri_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, n_inner: in
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
     pi = make_inputs(inputs)
-    _check(lib.rsv_fri_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, pi, len(list(inputs)), n_queries,
+    _check(lib.rsv_fri_paths(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), pi, len(list(inputs)), n_queries,
                              max_log, n_inner, sib.ctypes.data_as(_u32p), cols.ctypes.data_as(_u32p),
                              accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_fri_paths")
     return sib, cols, accept, reason
@@ -341,7 +406,13 @@ def fri_paths(proofs: Sequence[bytes], n_queries: int, max_log: int, n_inner: in
 
 class Context:
     """One HIP stream + reusable HBM workspace on one device (rsv_ctx).  Operates on torch tensors that
-    already live on that device; nothing is copied through the host."""
+    already live on that device; nothing is copied through the host.
+
+    Stream ordering: the context enqueues on its own non-blocking streams.  Every method that reads or writes
+    caller tensors first makes the context wait for torch's CURRENT stream (rsv_ctx_wait_stream), so tensors
+    produced by torch kernels / copies immediately before the call are complete when the verifier reads them, and
+    output buffers freshly allocated or zeroed by torch are not overwritten early.  Results are ordered for torch
+    by `synchronize()` (host blocks) or `release_to_torch()` (torch's current stream waits, host does not)."""
 
     def __init__(self, device: int = 0):
         h = ctypes.c_void_p()
@@ -367,26 +438,49 @@ class Context:
     def stream(self) -> int:
         return lib.rsv_ctx_stream(self._h) or 0
 
-    def poseidon2_permute(self, d_in, d_out):
-        n = d_in.numel() // 16
-        _check(lib.rsv_poseidon2_permute_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), n), "rsv_poseidon2_permute_dev")
+    def _torch_stream(self):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def verify_batch(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS,
-                     cfg: Optional[PcsConfig] = None):
+    def acquire_from_torch(self):
+        """Work enqueued so far on torch's current stream happens before what this context enqueues next."""
+        _check(lib.rsv_ctx_wait_stream(self._h, self._torch_stream()), "rsv_ctx_wait_stream")
+
+    def release_to_torch(self):
+        """torch's current stream waits for everything this context has enqueued so far (no host block)."""
+        _check(lib.rsv_stream_wait_ctx(self._h, self._torch_stream()), "rsv_stream_wait_ctx")
+
+    def prepare_cfg(self, cfg, n: int) -> PreparedCfg:
+        """Stage a configuration set for repeated use (the per-proof index of a mixed batch goes to HBM once)."""
+        def to_dev(a):
+            import torch
+            return torch.from_numpy(a).to(torch.device("cuda", self.device))
+        return prepare_cfg(cfg, n, to_dev)
+
+    def poseidon2_permute(self, d_in, d_out, d_bad=None):
+        n = d_in.numel() // 16
+        self.acquire_from_torch()
+        _check(lib.rsv_poseidon2_permute_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), n,
+                                             d_bad.data_ptr() if d_bad is not None else None), "rsv_poseidon2_permute_dev")
+
+    def verify_batch(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS):
         pi = make_inputs(inputs)
-        _check(lib.rsv_verify_batch_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n,
-                                        ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+        pc = self.prepare_cfg(cfg, n)
+        self.acquire_from_torch()
+        _check(lib.rsv_verify_batch_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
                "rsv_verify_batch_dev")
 
     def trace_paths(self, d_blob, d_offsets, n: int, n_queries: int, max_log: int, d_sib, d_pos, d_accept,
-                    d_reason=None, inputs=STANDARD_INPUTS):
+                    d_reason=None, cfg=None, inputs=STANDARD_INPUTS):
         pi = make_inputs(inputs)
-        _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
+        pc = self.prepare_cfg(cfg, n)
+        self.acquire_from_torch()
+        _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                        n_queries, max_log, d_sib.data_ptr(), d_pos.data_ptr(), d_accept.data_ptr(),
                                        d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
 
-    def verify_batch_host(self, proofs, inputs=STANDARD_INPUTS, cfg=None):
+    def verify_batch_host(self, proofs, cfg, inputs=STANDARD_INPUTS):
         """Proofs in host memory, one buffer each (bytes / numpy uint8 arrays): gather, upload and verify overlap
         (rsv_verify_batch_host).  Returns (accept, reason) numpy arrays."""
         n = len(proofs)
@@ -396,12 +490,12 @@ class Context:
         accept = np.zeros(n, np.uint8)
         reason = np.zeros(n, np.uint8)
         pi = make_inputs(inputs)
-        c = ctypes.byref(cfg) if cfg is not None else None
-        _check(lib.rsv_verify_batch_host(self._h, ptrs, lens.ctypes.data_as(_u64p), n, c, pi, len(list(inputs)),
+        pc = prepare_cfg(cfg, n)  # host residency: the library uploads the per-proof index chunk by chunk
+        _check(lib.rsv_verify_batch_host(self._h, ptrs, lens.ctypes.data_as(_u64p), n, pc.ref(), pi, len(list(inputs)),
                                          accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p)), "rsv_verify_batch_host")
         return accept, reason
 
-    def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
+    def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,
                      d_fri_cols=None, d_fri_folded=None):
         """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
@@ -410,10 +504,13 @@ class Context:
         ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
                       ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded))
         pi = make_inputs(inputs)
-        _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pi, len(list(inputs)),
+        pc = self.prepare_cfg(cfg, n)
+        self.acquire_from_torch()
+        _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")
 
     def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):
+        self.acquire_from_torch()
         _check(lib.rsv_accept_bitmap_dev(self._h, d_accept.data_ptr(), n, d_bitmap.data_ptr(),
                                          d_count.data_ptr() if d_count is not None else None), "rsv_accept_bitmap_dev")
 

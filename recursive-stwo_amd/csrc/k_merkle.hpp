@@ -11,15 +11,14 @@ namespace rsv {
 // (side stream): one lane per (proof, tree, row) hashes leaf-level row r counted from the start of
 // queried_values and lower-level row r counted from its END (where that block begins depends on how many
 // leaves are distinct, which is only known once the queries are).  k_trace_merkle then just picks its rows.
-//   rowh[((p*4 + t)*2 + 0)*G + r] = leaf hash of leaf row r
-//   rowh[((p*4 + t)*2 + 1)*G + r] = column capacity digest of the r-th LAST lower-level row
+//   rowh[((slot*4 + t)*2 + 0)*G + r] = leaf hash of leaf row r
+//   rowh[((slot*4 + t)*2 + 1)*G + r] = column capacity digest of the r-th LAST lower-level row
 struct RowHashArgs {
     const uint8_t* blob;
     const uint64_t* offsets;
     uint32_t n, G;         // slots in this launch, lanes per proof (= n_queries of the bucket)
     const ProofMeta* metas;
-    uint32_t* rowh;        // [proof][4][2][Grow][8]
-    uint32_t Grow;         // row stride of rowh (max n_queries of the batch)
+    uint32_t* rowh;        // [slot][4][2][G][8] (this bucket's part of the row-hash workspace)
     const uint32_t* ids;   // slot -> proof (nullptr: identity)
 };
 
@@ -40,10 +39,10 @@ __global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
     const uint32_t nc_lower = (t == 3 || A == B) ? 0u : (A < B ? plonk_cols(t) : poseidon_cols(t));
     const uint32_t* qv = w + m.qv_off[t];
     const uint32_t qv_n = m.qv_n[t];
-    uint32_t* out = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
+    uint32_t* out = a.rowh + (((size_t)slot * 4 + t) * 2) * G * 8;
     if ((r + 1) * nc_leaf <= qv_n) store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity(qv + r * nc_leaf, nc_leaf)));
     if (nc_lower && (r + 1) * nc_lower <= qv_n)
-        store_hash(out + ((size_t)a.Grow + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
+        store_hash(out + ((size_t)G + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
 }
 
 // ----------------------------------------------------------- k_trace_merkle
@@ -59,8 +58,7 @@ struct MerkleArgs {
     const uint32_t* leafv;
     uint32_t maxInner;
     uint32_t Lc;  // cap level: levels below Lc are hashed by merkle_cap (0 = walk every path to the root)
-    const uint32_t* rowh;  // k_row_hash output, [proof][4][2][Grow][8]
-    uint32_t Grow;
+    const uint32_t* rowh;  // k_row_hash output for the slots of this launch, [slot][4][2][G][8]
     // optional per-query authentication paths of the trace trees, transcript query order:
     //   path_sib[((slot*4 + t)*G + i)*maxM + k]  = sibling hash at the k-th level above the leaf (8 words)
     //   path_pos[(slot*4 + t)*G + i]              = position of query i at the tree's leaf level
@@ -197,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
         s_top = lvl_s(h->lvl[mx + 1]);
         nd_leaf = lvl_nd(h->lvl[mx]);
         qj = a.ctxs[p].q[j];
-        rows = a.rowh + (((size_t)p * 4 + t) * 2) * a.Grow * 8;
+        rows = a.rowh + (((size_t)slot_ * 4 + t) * 2) * G * 8;
         const uint32_t row = ent_rb(ent[mx * G + j]);
         if ((row + 1) * nc_leaf > qv_n) bad = true;
         else {
@@ -244,9 +242,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
                 // lower-level rows were hashed counting from the end of queried_values
                 const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
                 const uint32_t off = nd_leaf * nc_leaf + row * nc;
-                if (off + nc > qv_n || nd_lower - 1 - row >= a.Grow) bad = true;
+                if (off + nc > qv_n || nd_lower - 1 - row >= G) bad = true;
                 else {
-                    cur = combine_with_column(cur, load_hash(rows + ((size_t)a.Grow + (nd_lower - 1 - row)) * 8));
+                    cur = combine_with_column(cur, load_hash(rows + ((size_t)G + (nd_lower - 1 - row)) * 8));
                     if (a.path_cols) {
                         uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64 + nc_leaf;
                         const uint32_t* src = w + m->qv_off[t] + off;

@@ -43,7 +43,7 @@ __device__ inline void parse_fri_layer(WordReader& r, FriLayerRef& l) {
 }
 
 __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                                              uint32_t n, CfgOpt cfg, ProofMeta* __restrict__ metas,
+                                              uint32_t n, CfgSet cfg, ProofMeta* __restrict__ metas,
                                               ProofCtx* __restrict__ ctxs, uint32_t* __restrict__ summary,
                                               uint32_t* __restrict__ shape) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,8 +63,15 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     m.pow_bits = r.w[W_POW_BITS]; m.blowup = r.w[W_BLOWUP]; m.log_last = r.w[W_LOG_LAST];
     uint32_t nq = r.w[W_NQ];
     if (r.w[W_NQ + 1] != 0 || nq == 0 || nq > MAXQ) return;
-    if (cfg.present && (cfg.pow_bits != m.pow_bits || cfg.blowup != m.blowup || cfg.log_last != m.log_last || cfg.nq != nq))
-        return;
+    {
+        const uint32_t ci = cfg.cfg_of ? cfg.cfg_of[p] : 0u;
+        if (ci >= cfg.n) return;
+        // dynamic index into a by-value kernel argument: select with a uniform loop instead of scratch
+        uint32_t want[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < (uint32_t)MAX_CFGS; k++)
+            if (k == ci) { want[0] = cfg.c[k][0]; want[1] = cfg.c[k][1]; want[2] = cfg.c[k][2]; want[3] = cfg.c[k][3]; }
+        if (want[0] != m.pow_bits || want[1] != m.blowup || want[2] != m.log_last || want[3] != nq) return;
+    }
     uint32_t b = m.blowup, last = m.log_last;
     if (m.lp < 1 || m.lq < 1 || m.lp > 28 || m.lq > 28 || b < 1 || b > 16 || last > 16 || m.pow_bits > 30) return;
     uint32_t A = m.lp + b, B = m.lq + b, M = umax(m.lp + 1, m.lq + 2) + b;

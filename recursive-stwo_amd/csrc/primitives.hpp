@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_permute(const uint4* __restrict__ in, u
         s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w;
         over |= (v.x >= P) | (v.y >= P) | (v.z >= P) | (v.w >= P);
     }
-    if (over) atomicOr(bad, 1u);
+    if (over && bad) atomicOr(bad, 1u);
     poseidon2_inline(s);
 #pragma unroll
     for (int k = 0; k < 4; k++) out[4 * i + k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);

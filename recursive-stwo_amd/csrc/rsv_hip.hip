@@ -45,7 +45,7 @@ struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr, ev_ext = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
@@ -106,6 +106,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
         hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ids, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess) {
         rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
@@ -126,6 +127,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_tr) (void)hipEventDestroy(c->ev_tr);
     if (c->ev_ids) (void)hipEventDestroy(c->ev_ids);
     if (c->ev_query) (void)hipEventDestroy(c->ev_query);
+    if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->host_pipe) destroy_host_pipe(c->host_pipe);
@@ -145,22 +147,32 @@ int rsv_ctx_synchronize(rsv_ctx* c) {
 
 void* rsv_ctx_stream(rsv_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+// Ordering against the caller's own streams.  Every entry point forks its side stream off the main one (ev_fork), so
+// ordering the main stream is enough.
+int rsv_ctx_wait_stream(rsv_ctx* c, void* hip_stream) {
+    if (!c) return RSV_E_NULL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev_ext, static_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ext, 0));
+    return RSV_OK;
+}
+int rsv_stream_wait_ctx(rsv_ctx* c, void* hip_stream) {
+    if (!c) return RSV_E_NULL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev_ext, c->stream));
+    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), c->ev_ext, 0));
+    return RSV_OK;
+}
+
 // ---------------------------------------------------------------- a3
-int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_bad) {
     if (!c || (n && (!d_in || !d_out))) return RSV_E_NULL;
     if (n == 0) return RSV_OK;
     if (n > ((size_t)1 << 31)) return RSV_E_SIZE;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return RSV_E_SIZE;
     HIP_TRY(hipSetDevice(c->device));
-    // the range flag lives at the start of the workspace
-    if (c->ws_bytes < 256) {
-        if (c->ws) (void)hipFree(c->ws);
-        c->ws = nullptr; c->ws_bytes = 0;
-        HIP_TRY(hipMalloc(&c->ws, 1 << 20));
-        c->ws_bytes = 1 << 20;
-    }
-    uint32_t* bad = static_cast<uint32_t*>(c->ws);
     hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint4*>(d_in), reinterpret_cast<uint4*>(d_out), n, bad);
+                       reinterpret_cast<const uint4*>(d_in), reinterpret_cast<uint4*>(d_out), n, d_bad);
     HIP_TRY(hipGetLastError());
     return RSV_OK;
 }

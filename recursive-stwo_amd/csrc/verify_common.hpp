@@ -19,8 +19,14 @@ struct PubInput {
     uint32_t value[4];
 };
 
-struct CfgOpt {
-    uint32_t present, pow_bits, blowup, log_last, nq;
+// The PCS configurations the caller expects (rsv_cfg_set, include/rsv.h): a proof must carry exactly the configuration
+// its cfg_of entry names (entry 0 when cfg_of is null), else RSV_R_PARSE.  The reference never reads the configuration
+// from the proof (FiatShamirHints::new(&proof, config, ..), components/hints/src/fiat_shamir.rs:69-74).
+constexpr int MAX_CFGS = 16;
+struct CfgSet {
+    uint32_t n;
+    uint32_t c[MAX_CFGS][4];  // pow_bits, log_blowup_factor, log_last_layer_degree_bound, n_queries
+    const uint8_t* cfg_of;    // device pointer, one index per proof, or null
 };
 
 __device__ __forceinline__ QM31 ldq(const uint32_t* p) { return q_mk(p[0], p[1], p[2], p[3]); }

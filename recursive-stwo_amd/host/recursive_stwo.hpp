@@ -299,7 +299,9 @@ struct Hints {
     // a query at that layer is the proof's self column at the leaf level
     std::vector<std::pair<uint32_t, std::vector<SinglePairMerkleProof>>> inner_layers_merkle_proofs;
 
-    static Hints compute(const std::vector<uint8_t>& proof, const Inputs& inputs) {
+    // FiatShamirHints::new(&proof, config, &inputs) (components/hints/src/fiat_shamir.rs:69-74): the configuration is
+    // the caller's, never the words serialized in the proof
+    static Hints compute(const std::vector<uint8_t>& proof, const PcsConfig& config, const Inputs& inputs) {
         const ProofShape sh = ProofShape::of(proof);
         const uint32_t nq = sh.n_queries, M = sh.M, nt = 1 + sh.n_inner;
         std::vector<uint32_t> row(RSV_TRANSCRIPT_WORDS), tsib((size_t)4 * nq * M * 8), tpos(4 * nq), tcols((size_t)4 * nq * 64),
@@ -311,7 +313,9 @@ struct Hints {
         const uint64_t offsets[2] = {0, proof.size()};
         uint8_t accept = 0, reason = 0;
         auto pi = abi_inputs(inputs);
-        int st = rsv_verify_hints(proof.data(), offsets, 1, pi.data(), pi.size(), &ho, &accept, &reason, default_device());
+        const rsv_pcs_config abi_cfg = config.abi();
+        const rsv_cfg_set cfg_set{&abi_cfg, 1, nullptr};
+        int st = rsv_verify_hints(proof.data(), offsets, 1, &cfg_set, pi.data(), pi.size(), &ho, &accept, &reason, default_device());
         if (st == RSV_E_SIZE) throw VerificationError(RSV_R_PARSE);  // header shape and body disagree
         check(st, "rsv_verify_hints");
         if (!accept) throw VerificationError((rsv_reason)reason);
@@ -423,9 +427,30 @@ inline rsv_ctx* thread_context() {
 
 // The whole stage sequence of examples/single-proof/src/main.rs:48-82 on a batch.
 struct Verifier {
-    // accept[i] / reason[i] per proof; never throws for a bad proof.
-    static void verify_batch(const std::vector<std::vector<uint8_t>>& proofs, const std::optional<PcsConfig>& config,
+    // accept[i] / reason[i] per proof; never throws for a bad proof.  configs: ONE configuration for the whole batch or
+    // one per proof (the recursion chain of examples/multi-proofs/src/main.rs:173-295 mixes six); required — a proof
+    // whose header carries another configuration is rejected (RSV_R_PARSE), as the reference never reads it from there.
+    static void verify_batch(const std::vector<std::vector<uint8_t>>& proofs, const std::vector<PcsConfig>& configs,
                              const Inputs& inputs, std::vector<uint8_t>& accept, std::vector<uint8_t>& reason) {
+        if (configs.empty() || (configs.size() != 1 && configs.size() != proofs.size()))
+            throw DeviceError("verify_batch: one PcsConfig, or one per proof", RSV_E_SIZE);
+        // distinct configurations + per-proof index (rsv_cfg_set)
+        std::vector<rsv_pcs_config> table;
+        std::vector<uint8_t> cfg_of(configs.size() == 1 ? 0 : proofs.size());
+        for (size_t i = 0; i < configs.size(); i++) {
+            const rsv_pcs_config c = configs[i].abi();
+            size_t k = 0;
+            while (k < table.size() && !(table[k].pow_bits == c.pow_bits && table[k].log_blowup_factor == c.log_blowup_factor &&
+                                         table[k].log_last_layer_degree_bound == c.log_last_layer_degree_bound &&
+                                         table[k].n_queries == c.n_queries))
+                k++;
+            if (k == table.size()) {
+                if (table.size() == RSV_MAX_CFGS) throw DeviceError("verify_batch: too many distinct configurations", RSV_E_SIZE);
+                table.push_back(c);
+            }
+            if (!cfg_of.empty()) cfg_of[i] = (uint8_t)k;
+        }
+        const rsv_cfg_set cfg_set{table.data(), (uint32_t)table.size(), cfg_of.empty() ? nullptr : cfg_of.data()};
         // one buffer per proof, as the reference holds them: the library gathers, uploads and verifies in a pipeline
         std::vector<const uint8_t*> ptrs;
         std::vector<uint64_t> lens;
@@ -433,16 +458,14 @@ struct Verifier {
         accept.assign(proofs.size(), 0);
         reason.assign(proofs.size(), 0);
         auto pi = abi_inputs(inputs);
-        rsv_pcs_config cfg{};
-        if (config) cfg = config->abi();
-        check(rsv_verify_batch_host(thread_context(), ptrs.data(), lens.data(), proofs.size(), config ? &cfg : nullptr, pi.data(),
+        check(rsv_verify_batch_host(thread_context(), ptrs.data(), lens.data(), proofs.size(), &cfg_set, pi.data(),
                                     pi.size(), accept.data(), reason.data()),
               "rsv_verify_batch_host");
     }
     // Reference behaviour for one proof: returns on success, "panics" (throws) at the failing stage.
     static void verify(const std::vector<uint8_t>& proof, const PcsConfig& config, const Inputs& inputs) {
         std::vector<uint8_t> a, r;
-        verify_batch({proof}, config, inputs, a, r);
+        verify_batch({proof}, std::vector<PcsConfig>{config}, inputs, a, r);
         if (!a[0]) throw VerificationError((rsv_reason)r[0]);
     }
 };

@@ -1,11 +1,29 @@
-"""Multi-GPU host logic: one process per GPU, proofs sharded by contiguous index range, ONE exchange per
-batch (all-gather of the per-rank accept bitmaps over RCCL/xGMI; `torch.distributed` backend "nccl" on GPUs,
-"gloo" in the CPU tests).  There is no data-path collective: proofs are independent units."""
+"""Multi-GPU host logic: one process per GPU, proofs sharded by contiguous index range, ONE exchange per batch.
+
+Proofs are independent units, so there is no data-path collective: rank r verifies the contiguous
+shard [lo_r, hi_r) of the job on its own GPU, packs its verdicts into a bitmap (rsv_accept_bitmap_dev) and the
+ranks exchange
+    * one all-gather of the per-rank bitmaps (2 KiB per rank for 65 536 proofs: latency-bound, so ONE collective
+      of fixed-size slices rather than a ring of variable ones), and
+    * one all-reduce(sum) of the accept counts as a cross-check,
+over RCCL / xGMI (`torch.distributed` backend "nccl" IS RCCL on ROCm).  In the CPU tests and in the one-GPU
+rehearsal the same code runs over "gloo" (tensors staged through host memory, which gloo needs).
+
+`ShardedVerifier.step()` is the per-batch unit `bench.py` times and `tests/test_sharding.py` /
+`tests/test_multi_gpu.py` check; `launch_ranks()` starts the N rank processes of a one-node job for a caller
+that was itself started as a plain process (`python bench.py --gpus N`).
+"""
 from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
 
 
+# ----------------------------------------------------------------------------------------------- partition
 def shard_range(n_total: int, rank: int, world: int):
     """Contiguous [lo, hi) of proof indices owned by `rank`; sizes differ by at most one."""
     if not (0 <= rank < world):
@@ -32,21 +50,144 @@ def unpack_bitmap(words: np.ndarray, n: int) -> np.ndarray:
     return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:n]
 
 
+# ----------------------------------------------------------------------------------------------- exchange
+class BitmapExchange:
+    """The one collective step of a sharded batch.  Every rank contributes `slice_words` int32 words (the largest
+    shard's bitmap size; smaller shards leave the tail zero) and a count; afterwards every rank holds all slices.
+
+    Buffers are allocated once: `local` (this rank's slice — the verifier writes its bitmap straight into it),
+    `gathered` (world x slice_words), `count` (1 x int64: local accepts in, job total out)."""
+
+    def __init__(self, n_total: int, rank: int, world: int, dist, torch, device):
+        self.n_total, self.rank, self.world, self.dist, self.torch = n_total, rank, world, dist, torch
+        self.lo, self.hi = shard_range(n_total, rank, world)
+        self.slice_words = max(1, bitmap_words(shard_range(n_total, 0, world)[1]))  # rank 0 owns a largest shard
+        self.device = device
+        self.local = torch.zeros(self.slice_words, dtype=torch.int32, device=device)
+        self.gathered = torch.zeros(world * self.slice_words, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        if world > 1 and not dist.is_initialized():
+            raise RuntimeError("world > 1 needs an initialised process group (init_rank)")
+        backend = dist.get_backend() if dist.is_initialized() else None
+        # gloo moves host memory: stage device tensors through the host (CPU tests, one-GPU rehearsal)
+        self.stage = backend == "gloo" and getattr(device, "type", str(device)) != "cpu"
+        if self.stage:
+            self.h_local = torch.zeros(self.slice_words, dtype=torch.int32)
+            self.h_gathered = torch.zeros(world * self.slice_words, dtype=torch.int32)
+            self.h_count = torch.zeros(1, dtype=torch.int64)
+        self.collective = backend is not None
+
+    def run(self):
+        """all-gather `local` into `gathered`, all-reduce `count`.  The caller has ordered the producer of `local` /
+        `count` before torch's current stream (Context.release_to_torch) — collectives are enqueued there."""
+        if not self.collective:
+            self.gathered.copy_(self.local)
+            return
+        if self.stage:
+            self.h_local.copy_(self.local)
+            self.h_count.copy_(self.count)
+            self.dist.all_gather_into_tensor(self.h_gathered, self.h_local)
+            self.dist.all_reduce(self.h_count)
+            self.gathered.copy_(self.h_gathered)
+            self.count.copy_(self.h_count)
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.local)
+            self.dist.all_reduce(self.count)
+
+    def assemble(self) -> np.ndarray:
+        """The job's accept vector (uint8[n_total]) from the gathered slices; host side, outside the timed step."""
+        g = self.gathered.cpu().numpy().view(np.uint32).reshape(self.world, self.slice_words)
+        out = np.zeros(self.n_total, np.uint8)
+        for r in range(self.world):
+            lo, hi = shard_range(self.n_total, r, self.world)
+            out[lo:hi] = unpack_bitmap(g[r], hi - lo)
+        return out
+
+    def total_accepted(self) -> int:
+        return int(self.count.item())
+
+
 def gather_accept_bitmap(local_bitmap, n_total: int, rank: int, world: int, dist, torch):
-    """All-gather the per-rank bitmaps and reassemble the global accept vector (uint8[n_total]) on every rank.
-    `local_bitmap` is an int32 tensor (device of the process group's backend) holding this rank's shard bits.
-    Ranks own shards of different sizes (shard_range), so every rank pads to the largest shard's word count."""
-    max_words = bitmap_words(shard_range(n_total, 0, world)[1] - shard_range(n_total, 0, world)[0])
-    padded = torch.zeros(max_words, dtype=torch.int32, device=local_bitmap.device)
-    padded[: local_bitmap.numel()] = local_bitmap
-    gathered = torch.zeros(world * max_words, dtype=torch.int32, device=local_bitmap.device)
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, padded)
-    else:
-        gathered.copy_(padded)
-    g = gathered.cpu().numpy().view(np.uint32).reshape(world, max_words)
-    out = np.zeros(n_total, np.uint8)
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        out[lo:hi] = unpack_bitmap(g[r], hi - lo)
-    return out
+    """Functional form of BitmapExchange for a caller that already holds its shard's bitmap as an int32 tensor:
+    returns the job's accept vector (uint8[n_total]) on every rank."""
+    ex = BitmapExchange(n_total, rank, world, dist, torch, local_bitmap.device)
+    ex.local[: local_bitmap.numel()] = local_bitmap
+    ex.run()
+    return ex.assemble()
+
+
+class ShardedVerifier:
+    """Rank `rank` of a `world`-rank verification job of `n_total` proofs on ONE GPU.
+
+        sv = ShardedVerifier(rsv, n_total, rank, world, device_index, dist, torch)
+        sv.step(d_blob, d_offsets, cfg)         # this rank's shard, resident in HBM
+        accept = sv.exchange.assemble()           # whole job, every rank
+
+    step() = rsv_verify_batch_dev on the shard -> rsv_accept_bitmap_dev into the exchange slice -> all-gather +
+    all-reduce.  Nothing blocks the host: the verifier's stream is ordered before torch's current stream (on which
+    the collectives are enqueued) with an event."""
+
+    def __init__(self, rsv, n_total: int, rank: int, world: int, device_index: int, dist, torch):
+        self.rsv, self.torch = rsv, torch
+        dev = torch.device("cuda", device_index)
+        self.ctx = rsv.Context(device_index)
+        self.exchange = BitmapExchange(n_total, rank, world, dist, torch, dev)
+        self.n_local = self.exchange.hi - self.exchange.lo
+        self.d_accept = torch.zeros(max(self.n_local, 1), dtype=torch.uint8, device=dev)
+        self.d_reason = torch.zeros(max(self.n_local, 1), dtype=torch.uint8, device=dev)
+
+    def step(self, d_blob, d_offsets, cfg, inputs=None, hints=None):
+        kw = {} if inputs is None else {"inputs": inputs}
+        if hints:
+            self.ctx.verify_hints(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw, **hints)
+        else:
+            self.ctx.verify_batch(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw)
+        self.ctx.accept_bitmap(self.d_accept, self.n_local, self.exchange.local, self.exchange.count)
+        self.ctx.release_to_torch()
+        self.exchange.run()
+
+    def synchronize(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        self.ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------- launcher
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(script: str, argv, n_ranks: int, env=None) -> int:
+    """Start the `n_ranks` rank processes of a one-node job: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> script argv...` as a CHILD process, and return
+    its exit code.  The calling process must not have touched the GPU (it only waits); it is never replaced."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=e)
+
+
+def init_rank(torch, dist, rehearsal: bool = False):
+    """Per-rank setup from the torchrun environment: (rank, world, device_index).  Backend "nccl" (= RCCL) with the
+    rank's own GPU; in rehearsal mode (a one-GPU box) every rank uses cuda:0 and the exchange runs over gloo, since
+    RCCL refuses two ranks on one device."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    if world > 1 or os.environ.get("RSV_FORCE_PROCESS_GROUP") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    return rank, world, dev_index

@@ -19,6 +19,28 @@ def load_manifest():
         return json.load(f)["proofs"]
 
 
+class Cfg:
+    """PcsConfig literal of a fixture as written in the reference source (manifest.json cites file:line); both
+    bindings accept any object with these four attributes."""
+
+    def __init__(self, pow_bits, log_blowup_factor, log_last_layer_degree_bound, n_queries):
+        self.pow_bits, self.log_blowup_factor = pow_bits, log_blowup_factor
+        self.log_last_layer_degree_bound, self.n_queries = log_last_layer_degree_bound, n_queries
+
+    def __repr__(self):
+        return f"Cfg(pow={self.pow_bits}, blowup={self.log_blowup_factor}, last={self.log_last_layer_degree_bound}, nq={self.n_queries})"
+
+
+_DERIVED = {"small_proof_composition.bin": "small_proof.bin", "small_proof_dup_query.bin": "small_proof.bin"}
+
+
+def fixture_cfg(name):
+    """The configuration the reference verifies fixture `name` under (tests/golden/manifest.json)."""
+    name = _DERIVED.get(name, name)
+    e = next(e for e in load_manifest() if e["file"] == name)
+    return Cfg(e["pow_bits"], e["log_blowup_factor"], e["log_last_layer_degree_bound"], e["n_queries"])
+
+
 def read_proof(name):
     with open(os.path.join(GOLDEN, "proofs", name), "rb") as f:
         return f.read()

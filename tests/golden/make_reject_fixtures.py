@@ -35,12 +35,12 @@ def main():
     w[57] = (int(w[57]) + 1) % 0x7FFFFFFF  # first word of the first sampled value (samples start at word 51)
     comp = ob.grind_nonce(w.tobytes())
     open(os.path.join(HERE, "small_proof_composition.bin"), "wb").write(comp)
-    print("composition fixture:", ob.verify_batch([comp], [(1, (1, 0, 0, 0))]))
+    print("composition fixture:", ob.verify_batch([comp], ob.PcsConfig(20, 5, 2, 16), [(1, (1, 0, 0, 0))]))
     with mp.Pool(8) as pool:
         for res in pool.imap_unordered(_search, [(proof, k << 40) for k in range(1, 65)]):
             if res is not None:
                 open(os.path.join(HERE, "small_proof_dup_query.bin"), "wb").write(res)
-                print("dup-query fixture:", ob.verify_batch([res], [(1, (1, 0, 0, 0))]))
+                print("dup-query fixture:", ob.verify_batch([res], ob.PcsConfig(20, 5, 2, 16), [(1, (1, 0, 0, 0))]))
                 pool.terminate()
                 break
 

@@ -106,7 +106,7 @@ static void test_verify(const std::vector<uint8_t>& small) {
     auto bad = small;
     bad[30000] ^= 1;
     std::vector<uint8_t> acc, reason;
-    Verifier::verify_batch({small, bad}, config, inputs, acc, reason);
+    Verifier::verify_batch({small, bad}, {config}, inputs, acc, reason);
     EXPECT(acc[0] == 1 && acc[1] == 0 && reason[1] != 0);
 }
 
@@ -114,7 +114,8 @@ static void test_verify(const std::vector<uint8_t>& small) {
 // and verify every per-query path against its commitment.
 static void test_hints(const std::vector<uint8_t>& small) {
     Inputs inputs = {{1, QM31{1, 0, 0, 0}}};
-    Hints h = Hints::compute(small, inputs);
+    const PcsConfig config{20, FriConfig::make(2, 5, 16)};
+    Hints h = Hints::compute(small, config, inputs);
     EXPECT((h.fiat_shamir.z == QM31{1211683141, 437669427, 409200369, 1127771350}));
     EXPECT(h.fiat_shamir.raw_queries.size() == 16);
     for (int t = 0; t < 4; t++) {
@@ -142,7 +143,7 @@ static void test_hints(const std::vector<uint8_t>& small) {
     EXPECT(threw);
     // wrong public input: the hints constructor "panics" at the logup check
     threw = false;
-    try { Hints::compute(small, {{1, QM31{2, 0, 0, 0}}}); } catch (const VerificationError& e) { threw = e.reason == RSV_R_LOGUP; }
+    try { Hints::compute(small, config, {{1, QM31{2, 0, 0, 0}}}); } catch (const VerificationError& e) { threw = e.reason == RSV_R_LOGUP; }
     EXPECT(threw);
 }
 

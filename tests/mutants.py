@@ -34,6 +34,6 @@ if __name__ == "__main__":
         with open(os.path.join(root, "tests", "golden", "proofs", name), "rb") as f:
             proof = f.read()
         batch = mutants_of(proof, rng, 40) + [proof]
-        acc, reason = ob.verify_batch(batch)
+        acc, reason = ob.verify_batch(batch, ob.header_cfg(proof))  # the genuine fixture's header == its manifest configuration
         total += len(batch)
     print("sanitized oracle ran", total, "proofs with", os.path.basename(ob.lib._name))

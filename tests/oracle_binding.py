@@ -18,6 +18,10 @@ class PcsConfig(ctypes.Structure):
                 ("log_last_layer_degree_bound", ctypes.c_uint32), ("n_queries", ctypes.c_uint32)]
 
 
+class CfgSet(ctypes.Structure):  # rsv_cfg_set
+    _fields_ = [("cfgs", ctypes.POINTER(PcsConfig)), ("n_cfgs", ctypes.c_uint32), ("cfg_of", ctypes.c_void_p)]
+
+
 class PublicInput(ctypes.Structure):
     _fields_ = [("idx", ctypes.c_uint32), ("value", ctypes.c_uint32 * 4)]
 
@@ -37,7 +41,7 @@ lib.rsvo_poseidon2_half_permute.argtypes = [_u32p, _u32p, _u8p, _u32p, _u32p, sz
 lib.rsvo_merkle_hash_node.argtypes = [_u32p, _u32p, _u32p, sz, _u32p, sz]
 lib.rsvo_merkle_path_root.argtypes = [_u32p, _u32p, _u32p, _u32p, ctypes.c_uint32, _u32p, sz]
 lib.rsvo_transcript.argtypes = [_u8p, sz, _u32p, sz]
-lib.rsvo_verify_batch.argtypes = [_u8p, _u64p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput), sz, _u8p, _u8p]
+lib.rsvo_verify_batch.argtypes = [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u8p, _u8p]
 lib.rsvo_query_values.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz]
 lib.rsvo_qm31_mul.argtypes = [_u32p, _u32p, _u32p]
 lib.rsvo_qm31_inv.argtypes = [_u32p, _u32p]
@@ -134,23 +138,55 @@ def pack(proofs):
     return blob, offsets
 
 
-def verify_batch(proofs, inputs=STANDARD_INPUTS, cfg=None):
+def make_cfg_set(cfg, n):
+    """cfg: one PcsConfig-like object or a sequence of n of them -> (CfgSet, keep-alive tuple)."""
+    if cfg is None:
+        raise TypeError("a PcsConfig (or one per proof) is required")
+    per = [cfg] * 1 if hasattr(cfg, "pow_bits") else list(cfg)
+    key = lambda c: (int(c.pow_bits), int(c.log_blowup_factor), int(c.log_last_layer_degree_bound), int(c.n_queries))  # noqa: E731
+    table, index = [], {}
+    cfg_of = np.zeros(max(n, 1), np.uint8)
+    if not hasattr(cfg, "pow_bits"):
+        assert len(per) == n
+    for i, c in enumerate(per):
+        if key(c) not in index:
+            index[key(c)] = len(table)
+            table.append(key(c))
+        cfg_of[i] = index[key(c)]
+    if not table:
+        table = [(0, 0, 0, 0)]
+    arr = (PcsConfig * len(table))(*[PcsConfig(*k) for k in table])
+    of = cfg_of if len(table) > 1 else None
+    cs = CfgSet(ctypes.cast(arr, ctypes.POINTER(PcsConfig)), len(table), of.ctypes.data if of is not None else None)
+    return cs, (arr, of)
+
+
+def verify_batch(proofs, cfg, inputs=STANDARD_INPUTS):
     blob, offsets = pack(proofs)
     n = len(proofs)
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
     pi = make_inputs(inputs)
+    cs, _keep = make_cfg_set(cfg, n)
     rc = lib.rsvo_verify_batch(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n,
-                               ctypes.byref(cfg) if cfg is not None else None, pi, len(list(inputs)),
+                               ctypes.byref(cs), pi, len(list(inputs)),
                                accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p))
     if rc != 0:
         raise RuntimeError(f"rsvo_verify_batch -> {rc}")
     return accept, reason
 
 
+def header_cfg(proof: bytes) -> PcsConfig:
+    """The configuration words serialized in a proof (words 10..13).  For tests that build batches from
+    fixtures whose header is known to equal the manifest's configuration — never a substitute for the caller's
+    configuration in the product."""
+    w = np.frombuffer(proof[:56], dtype=np.uint32)
+    return PcsConfig(int(w[10]), int(w[11]), int(w[12]), int(w[13]))
+
+
 def perm_count(proof: bytes, inputs=STANDARD_INPUTS):
     lib.rsvo_perm_count_reset()
-    verify_batch([proof], inputs)
+    verify_batch([proof], header_cfg(proof), inputs)
     return int(lib.rsvo_perm_count())
 
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rsv):
     lib = ctypes.CDLL(rsv.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rsv.h but not exported by librsv_hip.so"
-    assert lib.rsv_abi_version() == 1
+    assert lib.rsv_abi_version() == 2
     assert sorted(rsv.EXPORTS) == declared_functions()
 
 
@@ -51,7 +51,7 @@ def test_no_cpu_fallback_without_gpu(rsv):
         rsv.poseidon2_permute(np.arange(16, dtype=np.uint32))
     assert e.value.code == -3  # RSV_E_DEVICE
     with pytest.raises(rsv.RsvError):
-        rsv.verify_batch([b"\0" * 64])
+        rsv.verify_batch([b"\0" * 64], rsv.PcsConfig(20, 5, 8, 16))
     with pytest.raises(rsv.RsvError):
         rsv.Context(0)
 

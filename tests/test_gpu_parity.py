@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_binding as ob
-from tests.conftest import load_manifest, read_proof
+from tests.conftest import fixture_cfg, load_manifest, read_proof
 
 pytestmark = pytest.mark.gpu
 P = 0x7FFFFFFF
@@ -115,8 +115,9 @@ def test_transcript_matches_oracle(rsv, entry):
 def test_all_fixtures_one_mixed_batch(rsv, manifest):
     std = [e for e in manifest if len(e["inputs"]) == 3]
     proofs = [read_proof(e["file"]) for e in std]
-    acc, reason = rsv.verify_batch(proofs)
-    oacc, oreason = ob.verify_batch(proofs)
+    cfgs = [fixture_cfg(e["file"]) for e in std]
+    acc, reason = rsv.verify_batch(proofs, cfgs)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
     for e, a in zip(std, acc):
         assert bool(a) == (e["expect"] == "ok"), e["file"]
@@ -127,11 +128,11 @@ def test_fixture_verdict(rsv, entry):
     proof = read_proof(entry["file"])
     cfg = rsv.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
                         entry["n_queries"])
-    acc, reason = rsv.verify_batch([proof], entry_inputs(entry), cfg)
+    acc, reason = rsv.verify_batch([proof], cfg, entry_inputs(entry))
     assert bool(acc[0]) == (entry["expect"] == "ok")
     ocfg = ob.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
                         entry["n_queries"])
-    oacc, oreason = ob.verify_batch([proof], entry_inputs(entry), ocfg)
+    oacc, oreason = ob.verify_batch([proof], ocfg, entry_inputs(entry))
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
 
 
@@ -141,8 +142,8 @@ def test_tampered_proofs_match_oracle(rsv, manifest, name, n_tamper):
     entry = next(e for e in manifest if e["file"] == name)
     proof = read_proof(name)
     batch = [ob.tamper(proof, i) for i in range(n_tamper)] + [proof]
-    acc, reason = rsv.verify_batch(batch, entry_inputs(entry))
-    oacc, oreason = ob.verify_batch(batch, entry_inputs(entry))
+    acc, reason = rsv.verify_batch(batch, fixture_cfg(name), entry_inputs(entry))
+    oacc, oreason = ob.verify_batch(batch, fixture_cfg(name), entry_inputs(entry))
     assert acc.tolist() == oacc.tolist()
     assert reason.tolist() == oreason.tolist()
     assert acc[-1] == 1 and acc[:-1].sum() == 0
@@ -150,13 +151,55 @@ def test_tampered_proofs_match_oracle(rsv, manifest, name, n_tamper):
 
 def test_wrong_inputs_and_config(rsv):
     proof = read_proof("small_proof.bin")
-    acc, reason = rsv.verify_batch([proof], [(1, (2, 0, 0, 0))])
+    cfg = fixture_cfg("small_proof.bin")
+    acc, reason = rsv.verify_batch([proof], cfg, [(1, (2, 0, 0, 0))])
     assert (acc[0], reason[0]) == (0, 3)
-    acc, reason = rsv.verify_batch([proof], [(1, (1, 0, 0, 0))], rsv.PcsConfig(20, 5, 2, 15))
+    acc, reason = rsv.verify_batch([proof], rsv.PcsConfig(20, 5, 2, 15), [(1, (1, 0, 0, 0))])
     assert (acc[0], reason[0]) == (0, 1)
     with pytest.raises(rsv.RsvError) as e:
-        rsv.verify_batch([proof], [(1, (P, 0, 0, 0))])
+        rsv.verify_batch([proof], cfg, [(1, (P, 0, 0, 0))])
     assert e.value.code == -5
+
+
+def test_lowered_security_words_are_rejected(rsv):
+    """a forger lowers pow_bits / n_queries / blowup / log_last in the proof header.  The GPU path
+    takes the configuration from the caller only: every such proof is RSV_R_PARSE, as in the oracle; and no
+    configuration at all is RSV_E_NULL on every verdict-producing entry point."""
+    import ctypes
+    from tests.test_oracle import security_downgrade_batch
+    batch = security_downgrade_batch()
+    cfg, inputs = fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))]
+    acc, reason = rsv.verify_batch(batch, cfg, inputs)
+    oacc, oreason = ob.verify_batch(batch, cfg, inputs)
+    assert acc.tolist() == oacc.tolist() == [0] * (len(batch) - 1) + [1]
+    assert reason.tolist() == oreason.tolist() == [1] * (len(batch) - 1) + [0]
+    # per-proof configurations: the right one accepts, another fixture's rejects, an index beyond the table rejects
+    good = read_proof("small_proof.bin")
+    acc, reason = rsv.verify_batch([good, good], [cfg, fixture_cfg("level1-5.bin")], inputs)
+    assert acc.tolist() == [1, 0] and reason.tolist() == [0, 1]
+    pc = rsv.PreparedCfg([cfg, fixture_cfg("level1-5.bin")], np.array([0, 9], np.uint8))
+    acc, reason = rsv.verify_batch([good, good], pc, inputs)
+    assert acc.tolist() == [1, 0] and reason.tolist() == [0, 1]
+    # NULL configuration: API misuse on the raw C-ABI
+    blob, offsets = rsv.pack([good])
+    a, r = np.zeros(1, np.uint8), np.zeros(1, np.uint8)
+    pi = rsv.make_inputs(inputs)
+    u8, u64 = rsv._u8p, rsv._u64p
+    assert rsv.lib.rsv_verify_batch(blob.ctypes.data_as(u8), offsets.ctypes.data_as(u64), 1, None, pi, 1, a.ctypes.data_as(u8),
+                                    r.ctypes.data_as(u8), 0) == -1
+    ho = rsv.HintsOut()
+    assert rsv.lib.rsv_verify_hints(blob.ctypes.data_as(u8), offsets.ctypes.data_as(u64), 1, None, pi, 1, ctypes.byref(ho),
+                                    a.ctypes.data_as(u8), r.ctypes.data_as(u8), 0) == -1
+    out = np.zeros(rsv.TRANSCRIPT_WORDS, np.uint32)
+    assert rsv.lib.rsv_transcript_batch(blob.ctypes.data_as(u8), offsets.ctypes.data_as(u64), 1, None, out.ctypes.data_as(rsv._u32p), 0) == -1
+    ctx = rsv.Context(0)
+    with pytest.raises(TypeError):
+        ctx.verify_batch_host([good], None)
+    ptrs = (ctypes.c_void_p * 1)(blob.ctypes.data)
+    lens = np.array([blob.size], np.uint64)
+    assert rsv.lib.rsv_verify_batch_host(ctx._h, ptrs, lens.ctypes.data_as(u64), 1, None, pi, 1, a.ctypes.data_as(u8), r.ctypes.data_as(u8)) == -1
+    assert rsv.lib.rsv_verify_batch_dev(ctx._h, 16, 16, 1, None, pi, 1, 16, 16) == -1
+    ctx.close()
 
 
 def test_truncated_garbage_and_empty(rsv):
@@ -164,11 +207,12 @@ def test_truncated_garbage_and_empty(rsv):
     rng = np.random.default_rng(7)
     batch = [proof[:cut] for cut in (0, 4, 60, 3580, len(proof) - 4)] + [proof + b"\0\0\0\0"]
     batch += [rng.integers(0, 256, 4096, dtype=np.uint8).tobytes(), proof]
-    acc, reason = rsv.verify_batch(batch, [(1, (1, 0, 0, 0))])
-    oacc, oreason = ob.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    cfg = fixture_cfg("small_proof.bin")
+    acc, reason = rsv.verify_batch(batch, cfg, [(1, (1, 0, 0, 0))])
+    oacc, oreason = ob.verify_batch(batch, cfg, [(1, (1, 0, 0, 0))])
     assert acc.tolist() == oacc.tolist() == [0] * 7 + [1]
     assert reason.tolist() == oreason.tolist()
-    acc, _ = rsv.verify_batch([], [(1, (1, 0, 0, 0))])
+    acc, _ = rsv.verify_batch([], cfg, [(1, (1, 0, 0, 0))])
     assert len(acc) == 0
 
 
@@ -177,10 +221,11 @@ def test_config2_batch_1024_copies(rsv):
     SURVEY §8d (proof i with i % 17 == 5 gets one flipped bit); verdicts bit-exact vs the oracle."""
     proof = read_proof("recursive_proof_16_15.bin")
     batch = [ob.tamper(proof, i) if i % 17 == 5 else proof for i in range(1024)]
-    acc, reason = rsv.verify_batch(batch)
+    cfg = fixture_cfg("recursive_proof_16_15.bin")
+    acc, reason = rsv.verify_batch(batch, cfg)
     # the oracle only needs to judge the distinct inputs
     tampered = [i for i in range(1024) if i % 17 == 5]
-    oacc, oreason = ob.verify_batch([batch[i] for i in tampered] + [proof])
+    oacc, oreason = ob.verify_batch([batch[i] for i in tampered] + [proof], cfg)
     want_acc = np.full(1024, oacc[-1], np.uint8)
     want_reason = np.full(1024, oreason[-1], np.uint8)
     want_acc[tampered] = oacc[:-1]
@@ -205,7 +250,7 @@ def test_device_resident_api_and_bitmap(rsv):
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
     ctx = rsv.Context(0)
     for _ in range(2):  # second call reuses the workspace
-        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason)
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=fixture_cfg("recursive_proof_16_15.bin"))
     ctx.accept_bitmap(d_acc, n, d_bitmap, d_count)
     ctx.synchronize()
     acc = d_acc.cpu().numpy()
@@ -216,6 +261,43 @@ def test_device_resident_api_and_bitmap(rsv):
     assert int(d_count.item()) == int(want.sum())
     times = ctx.last_stage_times()
     assert set(times) >= {"trace_merkle", "pair_merkle", "transcript"} and all(v >= 0 for v in times.values())
+    ctx.close()
+
+
+def test_blob_produced_by_torch_kernels_right_before_verify(rsv):
+    """the context runs on private non-blocking streams.  The batch is assembled by torch kernels
+    on torch's current stream (repeat, a long chain of in-place XORs that cancel out, a scatter that tampers) and the
+    verdict buffers are zeroed by torch, all WITHOUT a host synchronisation before the call: Context methods order
+    their stream after torch's (rsv_ctx_wait_stream), so the verdicts must be those of the finished blob."""
+    import torch
+    proof = read_proof("recursive_proof_16_15.bin")
+    n = 4096
+    dev = torch.device("cuda:0")
+    one = torch.from_numpy(np.frombuffer(proof, dtype=np.uint8).copy()).to(dev)
+    offsets = torch.arange(n + 1, dtype=torch.int64, device=dev) * len(proof)
+    ctx = rsv.Context(0)
+    cfg = ctx.prepare_cfg(fixture_cfg("recursive_proof_16_15.bin"), n)
+    tam = np.array([i for i in range(n) if i % 5 == 1], np.int64)
+    pos = torch.from_numpy(tam * len(proof) + 60 + (tam * 7919) % (len(proof) - 68)).to(dev)
+    torch.cuda.synchronize()
+    for side in (False, True):  # torch's default stream, then a side stream made current
+        stream = torch.cuda.Stream(dev) if side else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            d_blob = one.repeat(n)                      # 446 MB written by a torch kernel
+            for k in range(24):                         # ~20 GB of read-modify-write traffic in front of the verifier
+                d_blob ^= (k % 7) + 1
+            for k in range(24):
+                d_blob ^= (k % 7) + 1
+            d_blob[pos] = d_blob[pos] ^ 1
+            d_acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+            d_reason = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+            ctx.verify_batch(d_blob, offsets, n, d_acc, d_reason, cfg=cfg)
+            ctx.release_to_torch()                      # torch's stream now waits for the verdicts: no host block
+            acc = d_acc.to("cpu", non_blocking=False).numpy()
+        want = np.ones(n, np.uint8)
+        want[tam] = 0
+        assert np.array_equal(acc, want), (side, int((acc != want).sum()))
+        del d_blob
     ctx.close()
 
 
@@ -245,13 +327,13 @@ def test_fuzzed_headers_and_prefixes_match_oracle(rsv):
             b = bytearray(small)
             b[off:off + 8] = int(val).to_bytes(8, "little")
             batch.append(bytes(b))
-    acc, reason = rsv.verify_batch(batch, [(1, (1, 0, 0, 0))])
-    oacc, oreason = ob.verify_batch(batch, [(1, (1, 0, 0, 0))])
+    acc, reason = rsv.verify_batch(batch, fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
+    oacc, oreason = ob.verify_batch(batch, fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert acc.tolist() == oacc.tolist()
     assert reason.tolist() == oreason.tolist()
     batch2 = [_corrupt(big, rng, 3620, 2) for _ in range(16)] + [big]
-    acc, reason = rsv.verify_batch(batch2)
-    oacc, oreason = ob.verify_batch(batch2)
+    acc, reason = rsv.verify_batch(batch2, fixture_cfg("level2-1.bin"))
+    oacc, oreason = ob.verify_batch(batch2, fixture_cfg("level2-1.bin"))
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
     assert acc[-1] == 1
 
@@ -272,7 +354,7 @@ def test_chunked_workspace_matches_unchunked(rsv, monkeypatch):
         ctx = rsv.Context(0)
         d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
-        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, inputs=[(1, (1, 0, 0, 0))])
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=fixture_cfg("small_proof.bin"), inputs=[(1, (1, 0, 0, 0))])
         ctx.synchronize()
         results.append((d_acc.cpu().numpy().tolist(), d_reason.cpu().numpy().tolist()))
         ctx.close()
@@ -285,10 +367,11 @@ def test_cap_disabled_matches_cap_enabled(rsv, monkeypatch):
     """RSV_CAP=0 walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
     proof = read_proof("recursive_proof_16_15.bin")
     batch = [ob.tamper(proof, i) for i in range(48)] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
+    cfgs = [fixture_cfg("recursive_proof_16_15.bin")] * 49 + [fixture_cfg("level1-5.bin"), fixture_cfg("level12-1.bin")]
     monkeypatch.setenv("RSV_CAP", "0")
-    a0, r0 = rsv.verify_batch(batch)
+    a0, r0 = rsv.verify_batch(batch, cfgs)
     monkeypatch.setenv("RSV_CAP", "1")
-    a1, r1 = rsv.verify_batch(batch)
+    a1, r1 = rsv.verify_batch(batch, cfgs)
     assert a0.tolist() == a1.tolist() and r0.tolist() == r1.tolist()
     assert a1[-3:].tolist() == [1, 1, 1]
 
@@ -302,7 +385,7 @@ def test_trace_paths_match_oracle(rsv, manifest, name):
     M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
     inputs = entry_inputs(entry)
     osib, opos, depth = ob.trace_paths(proof, nq, M, inputs)
-    sib, pos, acc, reason = rsv.trace_paths([proof, proof], nq, M, inputs)
+    sib, pos, acc, reason = rsv.trace_paths([proof, proof], fixture_cfg(name), nq, M, inputs)
     assert acc.tolist() == [1, 1] and reason.tolist() == [0, 0]
     for k in range(2):
         assert np.array_equal(pos[k], opos)
@@ -311,7 +394,7 @@ def test_trace_paths_match_oracle(rsv, manifest, name):
             assert np.array_equal(sib[k, t, :, :d, :], osib[t, :, :d, :]), (k, t)
     # shape mismatch is an API error, not a verdict
     with pytest.raises(rsv.RsvError) as e:
-        rsv.trace_paths([proof], nq, M + 1, inputs)
+        rsv.trace_paths([proof], fixture_cfg(name), nq, M + 1, inputs)
     assert e.value.code == -2
 
 
@@ -324,8 +407,9 @@ def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
         assert rsv.transcript(proof) == rsv._parse_transcript(ob.transcript_raw(proof)), (mode, entry["file"])
     proof = read_proof("recursive_proof_16_15.bin")
     batch = [ob.tamper(proof, i) for i in range(40)] + [proof, read_proof("level1-5.bin"), read_proof("level13-1.bin")]
-    acc, reason = rsv.verify_batch(batch)
-    oacc, oreason = ob.verify_batch(batch)
+    cfgs = [fixture_cfg("recursive_proof_16_15.bin")] * 41 + [fixture_cfg("level1-5.bin"), fixture_cfg("level13-1.bin")]
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
 
 
@@ -339,7 +423,7 @@ def test_fri_paths_match_oracle(rsv, manifest, name):
     M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
     inputs = entry_inputs(entry)
     osib, ocols = ob.fri_paths(proof, nq, M, 1 + n_inner, inputs)
-    sib, cols, acc, reason = rsv.fri_paths([proof, proof], nq, M, n_inner, inputs)
+    sib, cols, acc, reason = rsv.fri_paths([proof, proof], fixture_cfg(name), nq, M, n_inner, inputs)
     assert acc.tolist() == [1, 1] and reason.tolist() == [0, 0]
     for k in range(2):
         assert np.array_equal(cols[k], ocols)
@@ -366,8 +450,8 @@ def test_every_length_prefix_mutated_matches_oracle(rsv, manifest, name):
     inputs = entry_inputs(entry)
     proof = read_proof(name)
     batch = _prefix_mutants(proof) + [proof]
-    acc, reason = rsv.verify_batch(batch, inputs)
-    oacc, oreason = ob.verify_batch(batch, inputs)
+    acc, reason = rsv.verify_batch(batch, fixture_cfg(name), inputs)
+    oacc, oreason = ob.verify_batch(batch, fixture_cfg(name), inputs)
     assert acc.tolist() == oacc.tolist()
     assert reason.tolist() == oreason.tolist()
     assert acc[-1] == 1 and int(acc[:-1].sum()) == 0
@@ -383,8 +467,8 @@ def test_structural_mutants_match_oracle(rsv, manifest, name):
     proof = read_proof(name)
     mut = ob.structural_mutants(proof)
     batch = [b for _, b in mut] + [proof]
-    acc, reason = rsv.verify_batch(batch, inputs)
-    oacc, oreason = ob.verify_batch(batch, inputs)
+    acc, reason = rsv.verify_batch(batch, fixture_cfg(name), inputs)
+    oacc, oreason = ob.verify_batch(batch, fixture_cfg(name), inputs)
     bad = [(mut[i][0], int(reason[i]), int(oreason[i])) for i in range(len(mut)) if reason[i] != oreason[i]]
     assert not bad, bad
     assert acc.tolist() == oacc.tolist()
@@ -408,13 +492,18 @@ def test_transcript_batch_matches_oracle(rsv, manifest):
     """FiatShamirHints rows for a mixed-shape batch: all fixtures, the SHA-256-channel fixture (parse reject), a
     proof with a flipped commitment byte (PoW reject) and garbage."""
     proofs = [read_proof(e["file"]) for e in manifest]
+    cfgs = [fixture_cfg(e["file"]) for e in manifest]
     bad = bytearray(proofs[0]); bad[70] ^= 1
     proofs += [read_proof("hybrid_hash.bin"), bytes(bad), b"\x00" * 64]
-    rows = rsv.transcript_batch(proofs)
+    cfgs += [fixture_cfg("hybrid_hash.bin"), cfgs[0], cfgs[0]]
+    rows = rsv.transcript_batch(proofs, cfgs)
     for i, pr in enumerate(proofs):
         want = _row_from_raw(ob.transcript_raw(pr)) if len(pr) >= 4096 else _row_from_raw(np.array([1], np.uint32))
         assert np.array_equal(rows[i], want), i
-    assert rsv.transcript_batch([b"\x00" * 64, b"\x01" * 8])[:, 0].tolist() == [1, 1]  # nothing parses
+    assert rsv.transcript_batch([b"\x00" * 64, b"\x01" * 8], cfgs[0])[:, 0].tolist() == [1, 1]  # nothing parses
+    # a proof presented under another fixture's configuration: its row says PARSE, nothing else
+    wrong = rsv.transcript_batch([proofs[0], proofs[1]], [cfgs[1], cfgs[1]])
+    assert wrong[0, 0] == 1 and not wrong[0, 1:].any() and np.array_equal(wrong[1], rows[1])
 
 
 def test_verify_hints_one_pass(rsv, manifest):
@@ -442,15 +531,16 @@ def test_verify_hints_one_pass(rsv, manifest):
     d_fc = torch.zeros((n, 1 + n_inner, nq, 3, 8), dtype=torch.int32, device=dev)
     d_ff = torch.zeros((n, 3, nq, 4), dtype=torch.int32, device=dev)
     ctx = rsv.Context(0)
-    ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq, M, n_inner), d_transcript=d_tr, d_trace_sib=d_ts,
+    cfg = fixture_cfg(entry["file"])
+    ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, cfg=cfg, shape=(nq, M, n_inner), d_transcript=d_tr, d_trace_sib=d_ts,
                      d_trace_pos=d_tp, d_trace_cols=d_tc, d_fri_sib=d_fs, d_fri_cols=d_fc, d_fri_folded=d_ff)
     ctx.synchronize()
-    oacc, oreason = ob.verify_batch(batch)
+    oacc, oreason = ob.verify_batch(batch, cfg)
     assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
     tr = d_tr.cpu().numpy().view(np.uint32)
-    assert np.array_equal(tr, rsv.transcript_batch(batch))
-    tsib, tpos, _, _ = rsv.trace_paths(batch, nq, M)
-    fsib, fcols, _, _ = rsv.fri_paths(batch, nq, M, n_inner)
+    assert np.array_equal(tr, rsv.transcript_batch(batch, cfg))
+    tsib, tpos, _, _ = rsv.trace_paths(batch, cfg, nq, M)
+    fsib, fcols, _, _ = rsv.fri_paths(batch, cfg, nq, M, n_inner)
     ok = np.nonzero(oacc)[0]
     assert np.array_equal(d_ts.cpu().numpy().view(np.uint32)[ok], tsib[ok]) and np.array_equal(d_tp.cpu().numpy().view(np.uint32)[ok], tpos[ok])
     assert np.array_equal(d_fs.cpu().numpy().view(np.uint32)[ok], fsib[ok]) and np.array_equal(d_fc.cpu().numpy().view(np.uint32)[ok], fcols[ok])
@@ -472,7 +562,7 @@ def test_verify_hints_one_pass(rsv, manifest):
         assert all(r.tolist() == words[17 + 8 * t:25 + 8 * t].tolist() for r in roots), t
     # a shape that does not match the batch is an API error, not a verdict
     with pytest.raises(rsv.RsvError):
-        ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, shape=(nq + 1, M, n_inner), d_trace_sib=d_ts, d_trace_pos=d_tp)
+        ctx.verify_hints(d_blob, d_off, n, d_acc, d_reason, cfg=cfg, shape=(nq + 1, M, n_inner), d_trace_sib=d_ts, d_trace_pos=d_tp)
     ctx.close()
 
 
@@ -481,25 +571,29 @@ def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
     """rsv_verify_batch_host: one host buffer per proof, gather -> upload -> verify pipelined over chunks.  A 1 MB
     chunk size forces dozens of chunks through the three-slot ring; verdicts == oracle's, in input order."""
     monkeypatch.setenv("RSV_HOST_CHUNK_MB", chunk_mb)
-    proofs = []
+    proofs, cfgs = [], []
     for e in manifest:
         pr = read_proof(e["file"])
         if entry_inputs(e) == list(rsv.STANDARD_INPUTS):
             proofs += [pr, ob.tamper(pr, len(proofs)), pr]
+            cfgs += [fixture_cfg(e["file"])] * 3
     proofs += [read_proof("hybrid_hash.bin"), b"\x00" * 64, b""]
+    cfgs += [fixture_cfg("hybrid_hash.bin"), cfgs[0], cfgs[0]]
     ctx = rsv.Context(0)
-    acc, reason = ctx.verify_batch_host(proofs)
-    oacc, oreason = ob.verify_batch(proofs)
+    acc, reason = ctx.verify_batch_host(proofs, cfgs)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
     assert int(acc.sum()) > 10
-    # misaligned length is an API error
-    with pytest.raises(rsv.RsvError):
-        ctx.verify_batch_host([b"\x00" * 6])
+    # a length that is not a whole number of words is a malformed proof like any other: RSV_R_PARSE for that proof only
+    acc1, reason1 = ctx.verify_batch_host([proofs[0], b"\x00" * 6, proofs[0]], cfgs[0])
+    assert acc1.tolist() == [1, 0, 1] and reason1.tolist() == [0, 1, 0]
     # an absurdly long buffer is not uploaded: RSV_R_PARSE, and its neighbours are unaffected
     big = np.zeros(40 << 20, np.uint8)
-    acc2, reason2 = ctx.verify_batch_host([proofs[0], big, proofs[0]])
+    acc2, reason2 = ctx.verify_batch_host([proofs[0], big, proofs[0]], cfgs[0])
     assert acc2.tolist() == [1, 0, 1] and reason2.tolist() == [0, 1, 0]
-    assert ctx.verify_batch_host([])[0].size == 0
+    assert ctx.verify_batch_host([], cfgs[0])[0].size == 0
+    with pytest.raises(TypeError):
+        ctx.verify_batch_host(proofs, None)
     ctx.close()
 
 
@@ -508,12 +602,14 @@ def test_mutant_corpus_matches_oracle(rsv, manifest):
     six fixtures of different shapes (n_queries 8..80) in ONE mixed batch: verdict and reason == oracle's."""
     from tests.mutants import mutants_of
     rng = np.random.default_rng(5)
-    batch = []
+    batch, cfgs = [], []
     for name in ("recursive_proof_16_15.bin", "level1-5.bin", "level5-1.bin", "level8-1.bin", "level10-1.bin", "level13-1.bin"):
         proof = read_proof(name)
-        batch += mutants_of(proof, rng, 60) + [proof]
-    acc, reason = rsv.verify_batch(batch)
-    oacc, oreason = ob.verify_batch(batch)
+        mut = mutants_of(proof, rng, 60) + [proof]
+        batch += mut
+        cfgs += [fixture_cfg(name)] * len(mut)
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
     diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
     assert diff.size == 0, [(int(i), int(reason[i]), int(oreason[i])) for i in diff[:10]]
     assert int(acc.sum()) >= 6
@@ -565,14 +661,17 @@ def test_plan_kernels_serial_and_parallel(rsv, manifest, monkeypatch):
     """The decommitment plan has two implementations — one lane per (proof, query) with bitmask popcounts (default)
     and the one-lane-per-proof walk it replaced (RSV_PLAN=serial).  Both must give the oracle's verdicts on the
     whole fixture set plus structural mutants (whose rejection reasons depend on the plan's witness counts)."""
-    proofs = [read_proof(e["file"]) for e in manifest if entry_inputs(e) == list(rsv.STANDARD_INPUTS)]
-    batch = list(proofs)
-    for pr in proofs[:4]:
-        batch += [b for _, b in ob.structural_mutants(pr)]
-    oacc, oreason = ob.verify_batch(batch)
+    std = [e for e in manifest if entry_inputs(e) == list(rsv.STANDARD_INPUTS)]
+    proofs = [read_proof(e["file"]) for e in std]
+    batch, cfgs = list(proofs), [fixture_cfg(e["file"]) for e in std]
+    for e, pr in list(zip(std, proofs))[:4]:
+        mut = [b for _, b in ob.structural_mutants(pr)]
+        batch += mut
+        cfgs += [fixture_cfg(e["file"])] * len(mut)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
     for mode in ("serial", "parallel"):
         monkeypatch.setenv("RSV_PLAN", mode)
-        acc, reason = rsv.verify_batch(batch)
+        acc, reason = rsv.verify_batch(batch, cfgs)
         assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), mode
 
 
@@ -581,8 +680,8 @@ def test_reject_fixtures_behind_the_proof_of_work(rsv):
     identity and the duplicate-query assertion, with the re-ground fixtures of tests/golden/make_reject_fixtures.py."""
     inputs = [(1, (1, 0, 0, 0))]
     batch = [read_proof("small_proof_composition.bin"), read_proof("small_proof.bin"), read_proof("small_proof_dup_query.bin")] * 3
-    acc, reason = rsv.verify_batch(batch, inputs)
-    oacc, oreason = ob.verify_batch(batch, inputs)
+    acc, reason = rsv.verify_batch(batch, fixture_cfg("small_proof.bin"), inputs)
+    oacc, oreason = ob.verify_batch(batch, fixture_cfg("small_proof.bin"), inputs)
     assert acc.tolist() == oacc.tolist() == [0, 1, 0] * 3
     assert reason.tolist() == oreason.tolist() == [4, 0, 5] * 3
 

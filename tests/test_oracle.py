@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_binding as ob
-from tests.conftest import load_manifest, read_proof
+from tests.conftest import fixture_cfg, load_manifest, read_proof
 
 P = 0x7FFFFFFF
 
@@ -99,11 +99,11 @@ def test_fixture_verdict(entry):
     inputs = [(i, tuple(v)) for i, v in entry["inputs"]]
     cfg = ob.PcsConfig(entry["pow_bits"], entry["log_blowup_factor"], entry["log_last_layer_degree_bound"],
                        entry["n_queries"])
-    acc, reason = ob.verify_batch([proof], inputs, cfg)
+    acc, reason = ob.verify_batch([proof], cfg, inputs)
     if entry["expect"] == "ok":
         assert acc[0] == 1 and reason[0] == 0
-        acc2, _ = ob.verify_batch([proof], inputs, None)
-        assert acc2[0] == 1
+        with pytest.raises(TypeError):  # the configuration is required: nothing is taken from the proof's header
+            ob.verify_batch([proof], None, inputs)
     else:
         assert acc[0] == 0 and reason[0] != 0
 
@@ -118,22 +118,22 @@ def test_permutation_counts():
 def test_wrong_config_rejected():
     proof = read_proof("small_proof.bin")
     cfg = ob.PcsConfig(20, 5, 2, 15)
-    acc, reason = ob.verify_batch([proof], [(1, (1, 0, 0, 0))], cfg)
+    acc, reason = ob.verify_batch([proof], cfg, [(1, (1, 0, 0, 0))])
     assert acc[0] == 0 and reason[0] == 1
 
 
 def test_wrong_public_input_rejected():
     proof = read_proof("small_proof.bin")
-    acc, reason = ob.verify_batch([proof], [(1, (2, 0, 0, 0))])
+    acc, reason = ob.verify_batch([proof], fixture_cfg("small_proof.bin"), [(1, (2, 0, 0, 0))])
     assert acc[0] == 0 and reason[0] == 3  # logup
-    acc, reason = ob.verify_batch([read_proof("recursive_proof_16_15.bin")], [(1, (1, 0, 0, 0))])
+    acc, reason = ob.verify_batch([read_proof("recursive_proof_16_15.bin")], fixture_cfg("recursive_proof_16_15.bin"), [(1, (1, 0, 0, 0))])
     assert acc[0] == 0 and reason[0] == 3
 
 
 def test_tampered_proofs_rejected():
     proof = read_proof("small_proof.bin")
     bad = [ob.tamper(proof, i) for i in range(40)]
-    acc, reason = ob.verify_batch(bad, [(1, (1, 0, 0, 0))])
+    acc, reason = ob.verify_batch(bad, fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert acc.sum() == 0
     assert set(reason.tolist()) <= set(range(1, 13))
     # several different stages must be hit (pow, trees, FRI first/inner, parse)
@@ -143,11 +143,11 @@ def test_tampered_proofs_rejected():
 def test_truncated_and_empty():
     proof = read_proof("small_proof.bin")
     for cut in (0, 4, 60, 3580, len(proof) - 4):
-        acc, reason = ob.verify_batch([proof[:cut]], [(1, (1, 0, 0, 0))])
+        acc, reason = ob.verify_batch([proof[:cut]], fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
         assert acc[0] == 0 and reason[0] == 1
-    acc, reason = ob.verify_batch([proof + b"\0\0\0\0"], [(1, (1, 0, 0, 0))])
+    acc, reason = ob.verify_batch([proof + b"\0\0\0\0"], fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert acc[0] == 0 and reason[0] == 1
-    acc, _ = ob.verify_batch([], [(1, (1, 0, 0, 0))])
+    acc, _ = ob.verify_batch([], fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert len(acc) == 0
 
 
@@ -262,7 +262,7 @@ def test_every_length_prefix_mutated_is_rejected():
             b = bytearray(proof)
             b[4 * pos:4 * pos + 8] = int(val).to_bytes(8, "little")
             batch.append(bytes(b))
-    acc, reason = ob.verify_batch(batch + [proof], [(1, (1, 0, 0, 0))])
+    acc, reason = ob.verify_batch(batch + [proof], fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert acc[-1] == 1 and int(acc[:-1].sum()) == 0
     assert set(reason[:-1].tolist()) <= set(range(1, 13))
 
@@ -272,7 +272,7 @@ def test_structural_mutants_fail_in_the_consuming_stage():
     (reasons: 6..9 = trace tree t, 10 = FRI first layer, 11 = FRI inner layers, 1 = parser's shape rules)."""
     proof = read_proof("small_proof.bin")
     mut = ob.structural_mutants(proof)
-    acc, reason = ob.verify_batch([b for _, b in mut], [(1, (1, 0, 0, 0))])
+    acc, reason = ob.verify_batch([b for _, b in mut], fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
     assert int(acc.sum()) == 0
     for (tag, _), r in zip(mut, reason.tolist()):
         if tag.startswith(("hw[", "qv[")):
@@ -415,9 +415,47 @@ def test_reject_fixtures_behind_the_proof_of_work():
     lay = ob.proof_layout(good)
     stale = bytearray(comp)
     stale[4 * lay["nonce_word"]:4 * lay["nonce_word"] + 8] = good[4 * lay["nonce_word"]:4 * lay["nonce_word"] + 8]
-    acc, reason = ob.verify_batch([comp, dup, good, bytes(stale)], inputs)
+    acc, reason = ob.verify_batch([comp, dup, good, bytes(stale)], fixture_cfg("small_proof.bin"), inputs)
     assert acc.tolist() == [0, 0, 1, 0] and reason.tolist() == [4, 5, 0, 2]
     # the duplicate really is one: the masked query positions of the re-ground transcript collide
     t = ob.transcript_raw(dup)
     q = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + 16] & ((1 << int(t[3])) - 1)
     assert len(set(q.tolist())) < 16 and t[0] == 0
+
+
+def _header_edit(proof, word, value):
+    b = bytearray(proof)
+    b[4 * word:4 * word + 4] = int(value).to_bytes(4, "little")
+    return bytes(b)
+
+
+def security_downgrade_batch():
+    """Proofs whose SERIALIZED configuration words were lowered by a forger (pow_bits 20 -> 0 / 1, n_queries 16 -> 1,
+    log_blowup 5 -> 1, log_last 2 -> 0): the verifier must not take its security level from them."""
+    proof = read_proof("small_proof.bin")
+    edits = [(10, 0), (10, 1), (10, 19), (13, 1), (13, 15), (11, 1), (11, 4), (12, 0), (12, 3)]
+    return [_header_edit(proof, w, v) for w, v in edits] + [_header_edit(_header_edit(proof, 13, 1), 11, 1), proof]
+
+
+def test_lowered_security_words_are_rejected():
+    """pow_bits / n_queries / blowup words lowered in the proof header.  Under the caller's
+    configuration every such proof is RSV_R_PARSE; pow_bits = 0 in the header must not turn the PoW check off."""
+    batch = security_downgrade_batch()
+    acc, reason = ob.verify_batch(batch, fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
+    assert acc.tolist() == [0] * (len(batch) - 1) + [1]
+    assert reason.tolist() == [1] * (len(batch) - 1) + [0]
+    # a per-proof configuration index outside the table rejects that proof only
+    cs, keep = ob.make_cfg_set([fixture_cfg("small_proof.bin"), fixture_cfg("level1-5.bin")], 2)
+    import ctypes
+    of = np.array([0, 7], np.uint8)
+    cs.cfg_of = of.ctypes.data
+    good = read_proof("small_proof.bin")
+    blob, offsets = ob.pack([good, good])
+    acc, reason = np.zeros(2, np.uint8), np.zeros(2, np.uint8)
+    pi = ob.make_inputs([(1, (1, 0, 0, 0))])
+    rc = ob.lib.rsvo_verify_batch(blob.ctypes.data_as(ob._u8p), offsets.ctypes.data_as(ob._u64p), 2, ctypes.byref(cs), pi, 1,
+                                  acc.ctypes.data_as(ob._u8p), reason.ctypes.data_as(ob._u8p))
+    assert rc == 0 and acc.tolist() == [1, 0] and reason.tolist() == [0, 1]
+    # no configuration at all is API misuse, not "trust the header"
+    assert ob.lib.rsvo_verify_batch(blob.ctypes.data_as(ob._u8p), offsets.ctypes.data_as(ob._u64p), 2, None, pi, 1,
+                                    acc.ctypes.data_as(ob._u8p), reason.ctypes.data_as(ob._u8p)) == -1

@@ -1,8 +1,10 @@
-"""N>1 host path on CPU: two gloo ranks shard a batch, verify their shards and all-gather the accept bitmaps.
-The verifier used inside the ranks is the CPU oracle (test infrastructure) — the GPU product path is
-exercised by tests/test_gpu_parity.py; this test covers sharding, bitmap packing and the collective."""
+"""N>1 host path on CPU: gloo ranks shard a job, verify their shards and run the product's exchange
+(recursive-stwo_amd/sharding.py: BitmapExchange — the object ShardedVerifier.step() and bench.py use).
+The verifier used inside the CPU ranks is the oracle (test infrastructure); the GPU product path through the very
+same exchange is covered by tests/test_multi_gpu.py (-m gpu).  This test covers the partition, the bitmap layout,
+the all-gather of unequal shards, the all-reduce of the count and the launcher's command line."""
+import importlib.util
 import os
-import socket
 import sys
 
 import numpy as np
@@ -11,22 +13,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def load_sharding():
+    spec = importlib.util.spec_from_file_location("rsv_sharding", os.path.join(ROOT, "recursive-stwo_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    return sh
 
 
 def _worker(rank, world, port, n_total, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("rsv_sharding", os.path.join(ROOT, "recursive-stwo_amd", "sharding.py"))
-    sh = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sh)
+    sh = load_sharding()
     from tests import oracle_binding as ob
     from tests.conftest import read_proof
 
@@ -34,22 +32,25 @@ def _worker(rank, world, port, n_total, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     proof = read_proof("small_proof.bin")
-    lo, hi = sh.shard_range(n_total, rank, world)
-    batch = [ob.tamper(proof, i) if i % 5 == 2 else proof for i in range(lo, hi)]
-    acc, _ = ob.verify_batch(batch, [(1, (1, 0, 0, 0))])
-    local = torch.from_numpy(sh.pack_bitmap(acc).view(np.int32).copy())
-    full = sh.gather_accept_bitmap(local, n_total, rank, world, dist, torch)
-    count = torch.tensor([int(acc.sum())], dtype=torch.int64)
-    dist.all_reduce(count)
-    q.put((rank, full.tolist(), int(count.item())))
+    ex = sh.BitmapExchange(n_total, rank, world, dist, torch, torch.device("cpu"))
+    batch = [ob.tamper(proof, i) if i % 5 == 2 else proof for i in range(ex.lo, ex.hi)]
+    acc, _ = ob.verify_batch(batch, ob.PcsConfig(20, 5, 2, 16), [(1, (1, 0, 0, 0))])
+    bits = sh.pack_bitmap(acc).view(np.int32)
+    results = []
+    for _ in range(2):  # the buffers are reused step after step
+        ex.local.zero_()
+        ex.local[: bits.size] = torch.from_numpy(bits.copy())
+        ex.count[0] = int(acc.sum())
+        ex.run()
+        results.append((ex.assemble().tolist(), ex.total_accepted()))
+    # the functional form on the same group
+    full = sh.gather_accept_bitmap(torch.from_numpy(bits.copy()), n_total, rank, world, dist, torch)
+    q.put((rank, results, full.tolist()))
     dist.destroy_process_group()
 
 
 def test_shard_range_partitions():
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("rsv_sharding", os.path.join(ROOT, "recursive-stwo_amd", "sharding.py"))
-    sh = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sh)
+    sh = load_sharding()
     for n in (0, 1, 7, 8, 65536, 1048576 + 3):
         for w in (1, 2, 3, 8):
             spans = [sh.shard_range(n, r, w) for r in range(w)]
@@ -62,21 +63,59 @@ def test_shard_range_partitions():
         sh.shard_range(4, 2, 2)
 
 
-@pytest.mark.timeout(180)
-def test_two_rank_gloo_bitmap_exchange():
+def test_single_rank_exchange_without_process_group():
+    """world == 1 and no process group: run() is a local copy (what `python bench.py` does at N = 1)."""
+    import torch
+    import torch.distributed as dist
+    sh = load_sharding()
+    ex = sh.BitmapExchange(70, 0, 1, dist, torch, torch.device("cpu"))
+    acc = (np.arange(70) % 3 != 0).astype(np.uint8)
+    ex.local[:] = torch.from_numpy(sh.pack_bitmap(acc).view(np.int32).copy())
+    ex.count[0] = int(acc.sum())
+    ex.run()
+    assert ex.assemble().tolist() == acc.tolist() and ex.total_accepted() == int(acc.sum())
+    with pytest.raises(RuntimeError):
+        sh.BitmapExchange(70, 0, 2, dist, torch, torch.device("cpu"))  # N > 1 needs init_rank first
+
+
+def test_launcher_command_line(monkeypatch):
+    """`python bench.py --gpus N` as a plain process: the parent starts `python -m torch.distributed.run` with the
+    driver's flags as a CHILD (subprocess, never exec) and returns its exit code."""
+    sh = load_sharding()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(sh.subprocess, "call", fake_call)
+    assert sh.launch_ranks("/x/bench.py", ["--gpus", "4", "--steps", "2"], 4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("n_total,world", [(23, 2), (64, 2), (7, 3)])
+def test_gloo_ranks_bitmap_exchange(n_total, world):
     import torch.multiprocessing as mp
+    sh = load_sharding()
     ctx = mp.get_context("spawn")
-    n_total, world = 23, 2
-    port = _free_port()
+    port = sh.free_port()
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=150) for _ in range(world)]
+    results = [q.get(timeout=200) for _ in range(world)]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
     want = [0 if i % 5 == 2 else 1 for i in range(n_total)]
-    for rank, full, count in results:
-        assert full == want, rank
-        assert count == sum(want)
+    for rank, steps, full in results:
+        for acc, count in steps:
+            assert acc == want, rank
+            assert count == sum(want)
+        assert full == want

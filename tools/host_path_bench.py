@@ -27,7 +27,9 @@ def main():
     import ctypes
     u8p, u64p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint64)
     ctx = rsv.Context(0)
-    ctx.verify_batch_host(proofs[:256])  # warm up: module load, workspace
+    std = rsv.PcsConfig(20, 5, 8, 16)  # standard_config, examples/multi-proofs/src/main.rs:173-176
+    pc = rsv.prepare_cfg(std, n)
+    ctx.verify_batch_host(proofs[:256], std)  # warm up: module load, workspace
     ptrs = (ctypes.c_void_p * n)(*[p.ctypes.data for p in proofs])
     lens = np.array([p.size for p in proofs], dtype=np.uint64)
     pi = rsv.make_inputs(rsv.STANDARD_INPUTS)
@@ -40,7 +42,7 @@ def main():
         os.environ["RSV_HOST_THREADS"] = thr
         acc[:] = 0
         t0 = time.perf_counter()
-        rc = rsv.lib.rsv_verify_batch_host(ctx._h, ptrs, lens.ctypes.data_as(u64p), n, None, pi, 3, acc.ctypes.data_as(u8p), None)
+        rc = rsv.lib.rsv_verify_batch_host(ctx._h, ptrs, lens.ctypes.data_as(u64p), n, pc.ref(), pi, 3, acc.ctypes.data_as(u8p), None)
         dt = time.perf_counter() - t0
         assert rc == 0 and int(acc.sum()) == n - len(range(5, n, 17))
         out[label] = {"s": dt, "proofs_per_s": n / dt, "GBps": total / dt / 1e9}
@@ -49,7 +51,7 @@ def main():
     offsets[1:] = np.cumsum([p.size for p in proofs], dtype=np.uint64)
     acc = np.zeros(n, np.uint8)
     t0 = time.perf_counter()
-    rc = rsv.lib.rsv_verify_batch(blob.ctypes.data_as(u8p), offsets.ctypes.data_as(u64p), n, None, pi, 3,
+    rc = rsv.lib.rsv_verify_batch(blob.ctypes.data_as(u8p), offsets.ctypes.data_as(u64p), n, pc.ref(), pi, 3,
                                   acc.ctypes.data_as(u8p), None, 0)
     dt = time.perf_counter() - t0
     assert rc == 0

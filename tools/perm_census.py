@@ -33,7 +33,7 @@ def main():
         for env in ("1", "0"):
             os.environ["RSV_CAP"] = env
             os.environ["RSV_TRANSCRIPT"] = "lane"
-            acc, _ = rsv.verify_batch([proof] * n)
+            acc, _ = rsv.verify_batch([proof] * n, ob.header_cfg(proof))  # genuine fixture: header == manifest configuration
             assert acc.all()
             per = counter()
             lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)
@@ -53,7 +53,7 @@ def mixed():
         want = sum(ob.perm_count(p) for p in proofs) / len(proofs)
         n = 4160 if label == "chain" else 4096
         counter()
-        acc, _ = rsv.verify_batch([proofs[i % len(proofs)] for i in range(n)])
+        acc, _ = rsv.verify_batch([proofs[i % len(proofs)] for i in range(n)], [ob.header_cfg(proofs[i % len(proofs)]) for i in range(n)])
         assert acc.all()
         per = counter()
         lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)

@@ -21,20 +21,24 @@ def main():
     n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["proofs"]
     rng = np.random.default_rng(2026)
-    batch = []
+    batch, cfgs = [], []
     for e in man:
         if [(i, tuple(v)) for i, v in e["inputs"]] != list(ob.STANDARD_INPUTS):
             continue
         proof = open(os.path.join(ROOT, "tests", "golden", "proofs", e["file"]), "rb").read()
-        batch += mutants_of(proof, rng, n_random) + [proof]
+        mut = mutants_of(proof, rng, n_random) + [proof]
+        batch += mut
+        # the reference's configuration literal of the fixture each mutant derives from (never the mutant's own header)
+        cfgs += [ob.PcsConfig(e["pow_bits"], e["log_blowup_factor"], e["log_last_layer_degree_bound"], e["n_queries"])] * len(mut)
     order = rng.permutation(len(batch))
     batch = [batch[i] for i in order]
+    cfgs = [cfgs[i] for i in order]
     t0 = time.perf_counter()
-    acc, reason = rsv.verify_batch(batch)
+    acc, reason = rsv.verify_batch(batch, cfgs)
     t1 = time.perf_counter()
     parts = np.array_split(np.arange(len(batch)), 16)
     with ThreadPoolExecutor(16) as ex:
-        res = list(ex.map(lambda ix: ob.verify_batch([batch[i] for i in ix]), parts))
+        res = list(ex.map(lambda ix: ob.verify_batch([batch[i] for i in ix], [cfgs[i] for i in ix]), parts))
     oacc = np.concatenate([r[0] for r in res])
     oreason = np.concatenate([r[1] for r in res])
     t2 = time.perf_counter()
