@@ -168,6 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
     __shared__ uint32_t xch[2][BLOCK][8];
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
+    __shared__ uint32_t xneed;
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot_ = blockIdx.x * per_block + grp;
@@ -215,15 +216,32 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
             d.root = w + W_COMMIT0 + 8 * t; d.flags = &a.ctxs[p].flags; d.fail_bit = R_MERKLE_T0 + t;
         }
     }
+    // Sibling exchange through LDS (and its workgroup barrier) only at the levels where some proof of this workgroup
+    // has two query paths that are siblings of each other: a level-l node has its sibling on a query path iff the
+    // number of distinct nodes grows from level l-1 to l.  Deep in the tree that is rare (16 proofs x 16 queries:
+    // ~1 workgroup in 10 at level 14), and a barrier per level makes every wave wait for the slowest of its four.
+    if (threadIdx.x == 0) xneed = 0;
+    __syncthreads();
+    if (live && j == 0) {
+        uint32_t mask = 0;
+        for (uint32_t l = Lc + 1; l <= mx; l++)
+            if (lvl_nd(h->lvl[l - 1]) < lvl_nd(h->lvl[l])) mask |= 1u << l;
+        if (mask) atomicOr(&xneed, mask);
+    }
+    __syncthreads();
+    const uint32_t need = xneed;
+    uint32_t buf = 0;  // toggles per exchange (not per level): a buffer is rewritten two barriers after its last read
     for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
-        const uint32_t buf = lvl & 1u;
         const bool on = live && lvl <= mx;
-        if (on) store_hash(xch[buf][threadIdx.x], cur);
-        __syncthreads();
+        const bool exch = (need >> lvl) & 1u;  // workgroup-uniform
+        if (exch) {
+            if (on) store_hash(xch[buf][threadIdx.x], cur);
+            __syncthreads();
+        }
         if (on) {
             uint32_t e = ent[lvl * G + j];
             Hash8 sib;
-            if (ent_sib(e) != 0xFFu) sib = load_hash(xch[buf][gbase + ent_sib(e)]);
+            if (exch && ent_sib(e) != 0xFFu) sib = load_hash(xch[buf][gbase + ent_sib(e)]);
             else {
                 uint32_t wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
                 if (wi < hw_n) sib = load_hash(hw + 8 * wi);
@@ -253,6 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
                 }
             }
         }
+        if (exch) buf ^= 1u;
     }
     if (live) {
         // every witness hash and queried value must be consumed (components/hints/src/decommit.rs:141-142)
@@ -276,10 +295,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     RSV_TAG(4);
-    __shared__ uint32_t xch[2][BLOCK][8];
-    __shared__ uint32_t xch2[BLOCK][8];  // path emission only: pre-column node hashes at data levels
+    __shared__ uint32_t xch[2][BLOCK][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
+    __shared__ uint32_t xcol[BLOCK][8];     // phase B (nodes with their column folded in), data levels only
+    __shared__ uint32_t xch2[BLOCK][8];     // path emission only: pre-column node hashes at data levels
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
+    __shared__ uint32_t xneed[2];
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot_ = blockIdx.x * per_block + grp;
@@ -333,21 +354,42 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
             d.root = w + L->commit_off; d.flags = &a.ctxs[p].flags; d.fail_bit = slot == 0 ? R_FRI_FIRST : R_FRI_INNER;
         }
     }
+    // Workgroup barriers only where lanes really exchange through LDS (see k_trace_merkle): [0] child levels at which
+    // some proof of this workgroup has sibling query paths, [1] child levels whose parent carries a column of the
+    // first-layer tree.  The column levels also take the phase-A barrier, which orders the reuse of xcol / xch2.
+    if (threadIdx.x < 2) xneed[threadIdx.x] = 0;
+    __syncthreads();
+    if (live && j == 0) {
+        uint32_t ma = 0, mb = 0;
+        for (uint32_t l = Lc + 1; l <= top; l++)
+            if (lvl_nd(h->lvl[l - 1]) < lvl_nd(h->lvl[l])) ma |= 1u << l;
+        if (slot == 0)
+            for (uint32_t g = 1; g < c->n_sizes; g++)
+                if (c->sizes[g] < top) mb |= 1u << (c->sizes[g] + 1u);
+        if (ma | mb) atomicOr(&xneed[0], ma | mb);
+        if (mb) atomicOr(&xneed[1], mb);
+    }
+    __syncthreads();
+    const uint32_t needA = xneed[0], needB = xneed[1];
+    uint32_t buf = 0;
     for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
         const bool on = live && lvl <= top;
         const uint32_t pl_ = lvl - 1;
+        const bool exA = (needA >> lvl) & 1u, exB = (needB >> lvl) & 1u;  // workgroup-uniform
         // is the parent level a data level of the first-layer tree?
         int dg = -1;
-        if (on && slot == 0)
+        if (on && exB)
             for (uint32_t g = 1; g < c->n_sizes; g++)
                 if (c->sizes[g] == pl_) dg = (int)g;
         // phase A: sibling hash at the child level
-        if (on && !have_sib) store_hash(xch[0][threadIdx.x], cur);
-        __syncthreads();
+        if (exA) {
+            if (on && !have_sib) store_hash(xch[buf][threadIdx.x], cur);
+            __syncthreads();
+        }
         if (on) {
             if (!have_sib) {
                 uint32_t e = ent[lvl * G + j];
-                if (ent_sib(e) != 0xFFu) sibh = load_hash(xch[0][gbase + ent_sib(e)]);
+                if (exA && ent_sib(e) != 0xFFu) sibh = load_hash(xch[buf][gbase + ent_sib(e)]);
                 else {
                     uint32_t wi;
                     if (slot == 0) wi = dg >= 0 ? (fl[dslot * G + j] & 0xFFFFu) : (uint32_t)h->wf[lvl] + ent_lb(e);
@@ -367,16 +409,17 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
             if (a.pair_sib) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
             cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
-            store_hash(xch[1][threadIdx.x], cur);
+            store_hash(xcol[threadIdx.x], cur);
         }
-        __syncthreads();
+        if (exA) buf ^= 1u;
+        if (exB) __syncthreads();
         if (on && dg >= 0) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
             uint32_t w_sib = fl[dslot * G + j] >> 16;
             if (w_sib == 0xFFFFu) {
                 uint32_t e = ent[pl_ * G + j];
                 if (ent_sib(e) != 0xFFu) {
-                    sibh = load_hash(xch[1][gbase + ent_sib(e)]);
+                    sibh = load_hash(xcol[gbase + ent_sib(e)]);
                     if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, load_hash(xch2[gbase + ent_sib(e)]));
                 } else bad = true;
             } else if (w_sib + 1 < L->hash_n) {

@@ -44,7 +44,7 @@ void destroy_host_pipe(HostPipe*);
 struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;  // k_scan (HBM-bound) runs here, underneath the latency-bound transcript
+    hipStream_t side = nullptr;  // row hashes, quotient constants, k_query, k_oods, k_scan: underneath the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr, ev_ext = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
