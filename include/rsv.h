@@ -166,6 +166,20 @@ int rsv_field_op(int op, const uint32_t* a4, const uint32_t* b4, uint32_t* out4,
  * PointCarryingQueryVar carries for position q[i] (primitives/query/src/lib.rs:57-168, circle/src/lib.rs:44-131;
  * reference test circle/src/lib.rs:264).  q[i] is masked to log_size bits; 1 <= log_size <= 30. */
 int rsv_domain_points(uint32_t log_size, const uint32_t* q, uint32_t* xy, size_t n, int device);
+/* a10 on its own: the OODS composition evaluation of CompositionCheck::compute
+ * (components/recursive/composition/src/lib.rs:60-120, plonk.rs:8-82, poseidon.rs:73-241) for n items.
+ *   samples4  [n][142][4]  the sampled values, flattened tree-major / column-major / sample-minor
+ *   params26  [n][26]      log_size_plonk, log_size_poseidon (1..28), plonk_total_sum, poseidon_total_sum, z, alpha,
+ *                          random_coeff, oods_point.x                          (QM31 = 4 words each)
+ *   out8      [n][8]       the accumulator over the 86 constraints | left + right * pi^(bound-2)(x): the proof passes
+ *                          the composition check iff the two are equal */
+int rsv_oods_eval(const uint32_t* samples4, const uint32_t* params26, uint32_t* out8, size_t n, int device);
+/* The last-layer comparison of FoldingResults::compute (components/recursive/folding/src/lib.rs:194-204) on its own:
+ * ok[i] = 1 iff the polynomial (2^log_n QM31 coefficients) evaluated at x[i] equals folded4[i] — the device function
+ * whose failure is RSV_R_FRI_LAST, a reason no mutated proof reaches (the polynomial is hashed before the proof of
+ * work, so every mutation stops earlier). */
+int rsv_last_layer_check(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, const uint32_t* folded4, uint8_t* ok,
+                         size_t n, int device);
 /* LinePolyVar::eval_at_point (primitives/line/src/lib.rs:39-67; reference test :82): one polynomial of 2^log_n
  * QM31 coefficients (log_n <= 16) evaluated at n points x[i] (M31). */
 int rsv_line_eval(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, uint32_t* out4, size_t n, int device);
@@ -282,6 +296,12 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  *   d_fri_folded [n][3][n_queries][4]       optional, with d_fri_sib: FirstLayerHints::folded_evals_by_column
  *                                           (components/hints/src/folding.rs:291-293) — the circle-to-line fold of
  *                                           each query's first-layer pair at the c-th column log size (descending)
+ *   d_query_values [n][n_queries][4*(8+n_inner)]  optional parity probe of rows a11 / a12 (values, not only verdicts),
+ *                                           per query in transcript order, QM31 each: the DEEP-quotient answers at
+ *                                           the (up to 3) column log sizes, descending (answer/src/lib.rs:294-315);
+ *                                           their circle-to-line folds (folding/src/lib.rs:57-90); the value entering
+ *                                           inner layer i, i < n_inner (:135-144); the value entering the last-layer
+ *                                           check and the last-layer polynomial evaluated at the query's point (:194-204)
  * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE. */
 #define RSV_TRANSCRIPT_WORDS 284
 typedef struct {
@@ -293,6 +313,7 @@ typedef struct {
     uint32_t* d_fri_sib;
     uint32_t* d_fri_cols;
     uint32_t* d_fri_folded;
+    uint32_t* d_query_values;
 } rsv_hints_out;
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,

@@ -745,8 +745,9 @@ static void evaluate_poseidon(eval_ctx* e, const qm31* pre, const qm31* tr) {
 /* sample offsets of each tree inside proof_view.samples */
 enum { S_T0 = 0, S_T1 = 50, S_T2 = 110, S_T3 = 134 };
 
-/* CompositionCheck::compute (composition/src/lib.rs:34-121) */
-static int check_composition(const proof_view* v, const transcript* t) {
+/* CompositionCheck::compute (composition/src/lib.rs:34-121): the accumulator over the 86 constraints and the value
+ * the committed composition polynomial gives at the OODS point */
+static void eval_composition(const proof_view* v, const transcript* t, qm31* acc_out, qm31* expected_out) {
     eval_ctx e; memset(&e, 0, sizeof e);
     e.rc = t->random_coeff; e.z = t->z; e.alpha = t->alpha; e.alpha2 = q_mul(t->alpha, t->alpha);
     /* plonk: pre cols 0..10, trace 0..12, interaction samples 0..12 (4 + 4*2) */
@@ -762,8 +763,41 @@ static int check_composition(const proof_view* v, const transcript* t) {
     const qm31* c = v->samples + S_T3;
     qm31 left = q_combine_ef(c[0], c[1], c[2], c[3]), right = q_combine_ef(c[4], c[5], c[6], c[7]);
     uint32_t comp_log_degree_bound = umax(v->lp + 2, v->lq + 3);
-    qm31 expected = q_add(left, q_mul(right, q_double_x(t->oods.x, comp_log_degree_bound - 2)));
-    return q_eq(e.acc, expected);
+    *expected_out = q_add(left, q_mul(right, q_double_x(t->oods.x, comp_log_degree_bound - 2)));
+    *acc_out = e.acc;
+}
+static int check_composition(const proof_view* v, const transcript* t) {
+    qm31 acc, expected;
+    eval_composition(v, t, &acc, &expected);
+    return q_eq(acc, expected);
+}
+/* Probe (rsv_oods_eval's counterpart): item i = 142 sampled values (4 words each) + 26 parameter words
+ * lp, lq, plonk_sum, poseidon_sum, z, alpha, random_coeff, oods.x; out = accumulator | expected (8 words). */
+int rsvo_oods_eval(const uint32_t* samples4, const uint32_t* params26, uint32_t* out8, size_t n) {
+    if (n && (!samples4 || !params26 || !out8)) return RSV_E_NULL;
+    if (!canonical(samples4, n * N_SAMPLES * 4)) return RSV_E_RANGE;
+    proof_view* v = calloc(1, sizeof *v);
+    transcript* t = calloc(1, sizeof *t);
+    int rc = RSV_OK;
+    for (size_t i = 0; i < n && rc == RSV_OK; i++) {
+        const uint32_t* pr = params26 + 26 * i;
+        if (pr[0] < 1 || pr[0] > 28 || pr[1] < 1 || pr[1] > 28 || !canonical(pr + 2, 24)) { rc = RSV_E_RANGE; break; }
+        v->lp = pr[0]; v->lq = pr[1];
+        v->plonk_sum = q_mk(pr[2], pr[3], pr[4], pr[5]); v->poseidon_sum = q_mk(pr[6], pr[7], pr[8], pr[9]);
+        t->z = q_mk(pr[10], pr[11], pr[12], pr[13]); t->alpha = q_mk(pr[14], pr[15], pr[16], pr[17]);
+        t->random_coeff = q_mk(pr[18], pr[19], pr[20], pr[21]); t->oods.x = q_mk(pr[22], pr[23], pr[24], pr[25]);
+        for (int k = 0; k < N_SAMPLES; k++) {
+            const uint32_t* w = samples4 + (i * N_SAMPLES + (size_t)k) * 4;
+            v->samples[k] = q_mk(w[0], w[1], w[2], w[3]);
+        }
+        qm31 acc, expected;
+        eval_composition(v, t, &acc, &expected);
+        uint32_t* o = out8 + 8 * i;
+        o[0] = acc.a.a; o[1] = acc.a.b; o[2] = acc.b.a; o[3] = acc.b.b;
+        o[4] = expected.a.a; o[5] = expected.a.b; o[6] = expected.b.a; o[7] = expected.b.b;
+    }
+    free(v); free(t);
+    return rc;
 }
 
 /* logup total-sum check, fiat_shamir/src/lib.rs:133-141 */
@@ -1063,6 +1097,8 @@ typedef struct {
     qm31 answers[3][MAX_QUERIES];
     qm31 last_value[MAX_QUERIES];
     qm31 first_folded[3][MAX_QUERIES]; /* FirstLayerHints::folded_evals_by_column, per size group and query */
+    qm31 inner_in[MAX_LAYERS][MAX_QUERIES]; /* value entering inner layer i (the query's own leaf of that layer's tree) */
+    qm31 last_eval[MAX_QUERIES];            /* last-layer polynomial at the query's point */
     uint32_t n_sizes;
     /* optional: per-path extraction of the trace trees (rsvo_trace_paths) */
     tree_record* records; /* [4] or NULL */
@@ -1221,6 +1257,7 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
                 qm31 a2 = q_mul(t->fri_alphas[i], t->fri_alphas[i]);
                 for (uint32_t j = 0; j < nq; j++) folded[j] = q_add(q_mul(a2, folded[j]), first[gi][j]);
             }
+        for (uint32_t j = 0; j < nq; j++) probe->inner_in[i][j] = folded[j];
         l -= 1;
         const fri_layer_view* L = &v->inner[i];
         uint32_t ps[2 * MAX_QUERIES], np = 0, pq[MAX_QUERIES];
@@ -1264,7 +1301,8 @@ static uint8_t verify_one(const uint8_t* bytes, size_t len, const rsv_pcs_config
             uint32_t idx = (qM[j] >> (M - l)) >> 1;
             m31 x = half_odds_at(ll, bit_reverse(idx, ll)).x, d[32];
             for (uint32_t k = 0; k < log_n; k++) { d[k] = x; x = m_sub(m_add(m_mul(x, x), m_mul(x, x)), 1); }
-            if (!q_eq(line_fold(v->last_coeffs, v->n_last, d), folded[j])) reason = RSV_R_FRI_LAST;
+            probe->last_eval[j] = line_fold(v->last_coeffs, v->n_last, d);
+            if (!q_eq(probe->last_eval[j], folded[j])) reason = RSV_R_FRI_LAST;
         }
     }
 done:
@@ -1316,6 +1354,38 @@ int rsvo_query_values(const uint8_t* proof, size_t len, const rsv_public_input* 
         }
     }
     rc = (int)o;
+done:
+    free(pr); free(v);
+    return rc;
+}
+
+/* The layout of rsv_hints_out::d_query_values for one proof: out [nq][4 * (8 + n_inner)], per query (transcript
+ * order) answers[3] | first-layer folds[3] | value entering inner layer i | value entering the last-layer check |
+ * last-layer polynomial at the query's point. */
+int rsvo_query_dump(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out, size_t cap,
+                    uint32_t* n_inner_out, uint32_t* nq_out) {
+    if (!proof || !out) return RSV_E_NULL;
+    query_probe* pr = calloc(1, sizeof *pr);
+    proof_view* v = malloc(sizeof *v);
+    int rc = RSV_OK;
+    if (!parse_proof(proof, len, NULL, v)) { rc = RSV_E_SIZE; goto done; }
+    uint8_t r = verify_one(proof, len, NULL, pi, n_pi, pr);
+    if (r != RSV_R_OK && r != RSV_R_FRI_LAST) { rc = RSV_E_SIZE; goto done; }
+    const uint32_t nq = v->cfg.n_queries, ni = v->n_inner;
+    const size_t stride = 4 * (8 + (size_t)ni);
+    if (cap < nq * stride) { rc = RSV_E_CAP; goto done; }
+    memset(out, 0, 4 * nq * stride);
+    for (uint32_t j = 0; j < nq; j++) {
+        uint32_t* o = out + j * stride;
+#define PUT(off, q) do { o[off] = (q).a.a; o[(off) + 1] = (q).a.b; o[(off) + 2] = (q).b.a; o[(off) + 3] = (q).b.b; } while (0)
+        for (uint32_t g = 0; g < pr->n_sizes; g++) { PUT(4 * g, pr->answers[g][j]); PUT(12 + 4 * g, pr->first_folded[g][j]); }
+        for (uint32_t i = 0; i < ni; i++) PUT(24 + 4 * i, pr->inner_in[i][j]);
+        PUT(24 + 4 * ni, pr->last_value[j]);
+        PUT(28 + 4 * ni, pr->last_eval[j]);
+#undef PUT
+    }
+    if (n_inner_out) *n_inner_out = ni;
+    if (nq_out) *nq_out = nq;
 done:
     free(pr); free(v);
     return rc;

@@ -49,6 +49,7 @@ void rsvo_qm31_inv(const uint32_t* a, uint32_t* out);
 /* CanonicCoset(log).circle_domain().at(bit_reverse(q, log)) -> (x, y). */
 void rsvo_domain_point(uint32_t log_size, uint32_t q, uint32_t* xy);
 int rsvo_field_op(int op, const uint32_t* a4, const uint32_t* b4, uint32_t* out4, size_t n);
+int rsvo_oods_eval(const uint32_t* samples4, const uint32_t* params26, uint32_t* out8, size_t n);
 int rsvo_line_eval(const uint32_t* coeffs4, uint32_t log_n, const uint32_t* x, uint32_t* out4, size_t n);
 /* Per-query intermediate values of one proof (for kernel-level parity tests):
  * out receives, for every query j in transcript order, the DEEP-quotient
@@ -64,6 +65,8 @@ int rsvo_trace_paths(const uint8_t* proof, size_t len, const rsv_public_input* p
                      size_t cap, uint32_t* pos, uint32_t* depth4, uint32_t* n_queries);
 int rsvo_trace_cols(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* cols, size_t cap,
                     uint32_t* n_queries);
+int rsvo_query_dump(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out, size_t cap,
+                    uint32_t* n_inner_out, uint32_t* nq_out);
 int rsvo_fri_folded(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out, size_t cap,
                     uint32_t* n_sizes, uint32_t* n_queries);
 

@@ -117,7 +117,7 @@ class HintsOut(ctypes.Structure):  # rsv_hints_out
     _fields_ = [("n_queries", ctypes.c_uint32), ("max_log", ctypes.c_uint32), ("n_inner", ctypes.c_uint32),
                 ("d_transcript", ctypes.c_void_p), ("d_trace_sib", ctypes.c_void_p), ("d_trace_pos", ctypes.c_void_p),
                 ("d_trace_cols", ctypes.c_void_p), ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p),
-                ("d_fri_folded", ctypes.c_void_p)]
+                ("d_fri_folded", ctypes.c_void_p), ("d_query_values", ctypes.c_void_p)]
 
 
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
@@ -163,6 +163,8 @@ def _load() -> ctypes.CDLL:
         "rsv_field_op": (ctypes.c_int, [ctypes.c_int, _u32p, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_domain_points": (ctypes.c_int, [ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
         "rsv_line_eval": (ctypes.c_int, [_u32p, ctypes.c_uint32, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_oods_eval": (ctypes.c_int, [_u32p, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_last_layer_check": (ctypes.c_int, [_u32p, ctypes.c_uint32, _u32p, _u32p, _u8p, sz, ctypes.c_int]),
         "rsv_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(CfgSet),
                                                  ctypes.POINTER(PublicInput), sz, _u8p, _u8p]),
         "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
@@ -190,7 +192,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
-           "rsv_line_eval",
+           "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
            "rsv_transcript_batch"]
 
 
@@ -266,6 +268,29 @@ def line_eval(coeffs, x, device: int = 0) -> np.ndarray:
     _check(lib.rsv_line_eval(c.ctypes.data_as(_u32p), log_n, xx.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), xx.size,
                              device), "rsv_line_eval")
     return out
+
+
+def oods_eval(samples, params, device: int = 0) -> np.ndarray:
+    """a10 probe (rsv_oods_eval): samples (n, 142, 4), params (n, 26) = lp, lq, plonk_sum, poseidon_sum, z, alpha,
+    random_coeff, oods.x -> (n, 8): constraint accumulator | expected value."""
+    sm = _u32(samples).reshape(-1, 142, 4)
+    pr = _u32(params).reshape(-1, 26)
+    out = np.empty((sm.shape[0], 8), np.uint32)
+    _check(lib.rsv_oods_eval(sm.ctypes.data_as(_u32p), pr.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), sm.shape[0], device),
+           "rsv_oods_eval")
+    return out
+
+
+def last_layer_check(coeffs, x, folded, device: int = 0) -> np.ndarray:
+    """ok[i] = 1 iff LinePoly(coeffs)(x[i]) == folded[i] (rsv_last_layer_check; the RSV_R_FRI_LAST comparison)."""
+    c = _u32(coeffs).reshape(-1, 4)
+    log_n = int(c.shape[0]).bit_length() - 1
+    xx = _u32(x).reshape(-1)
+    f = _u32(folded).reshape(-1, 4)
+    ok = np.zeros(xx.size, np.uint8)
+    _check(lib.rsv_last_layer_check(c.ctypes.data_as(_u32p), log_n, xx.ctypes.data_as(_u32p), f.ctypes.data_as(_u32p),
+                                    ok.ctypes.data_as(_u8p), xx.size, device), "rsv_last_layer_check")
+    return ok
 
 
 def half_permute(left, right, swap=None, device: int = 0):
@@ -497,12 +522,12 @@ class Context:
 
     def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,
-                     d_fri_cols=None, d_fri_folded=None):
+                     d_fri_cols=None, d_fri_folded=None, d_query_values=None):
         """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
         shape = (n_queries, max_log, n_inner), needed for the path outputs."""
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
-                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded))
+                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded), ptr(d_query_values))
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(cfg, n)
         self.acquire_from_torch()

@@ -10,33 +10,35 @@ namespace rsv {
 struct EvalCtx {
     QM31 rc, acc, dinv, z, alpha, alpha2, shift;
     QM31 fp[5], fq[5];
-    int n_fracs;
     const uint32_t* w;
     int inter;  // next interaction sample index
     __device__ QM31 smp(int k) const { return ldq(w + SAMPLES.off[k]); }
     // data_structures.rs:26-28,166-169
     __device__ void constraint(QM31 v) { acc = q_add(q_mul(acc, rc), q_mul(v, dinv)); }
-    // data_structures.rs:147-164
-    __device__ void relation(QM31 mult, QM31 v0, QM31 v1) {
-        fp[n_fracs] = mult;
-        fq[n_fracs++] = q_sub(q_add(v0, q_mul(alpha, v1)), z);
+    // data_structures.rs:147-164.  K (the fraction's index) and the batch geometry below are compile-time constants so
+    // that fp / fq stay in registers (a run-time index would send them to scratch memory).
+    template <int K> __device__ __forceinline__ void relation(QM31 mult, QM31 v0, QM31 v1) {
+        fp[K] = mult;
+        fq[K] = q_sub(q_add(v0, q_mul(alpha, v1)), z);
     }
-    __device__ void relation(QM31 mult, QM31 v0, QM31 v1, QM31 v2) {
-        fp[n_fracs] = mult;
-        fq[n_fracs++] = q_sub(q_add(q_add(v0, q_mul(alpha, v1)), q_mul(alpha2, v2)), z);
+    template <int K> __device__ __forceinline__ void relation(QM31 mult, QM31 v0, QM31 v1, QM31 v2) {
+        fp[K] = mult;
+        fq[K] = q_sub(q_add(q_add(v0, q_mul(alpha, v1)), q_mul(alpha2, v2)), z);
     }
-    // data_structures.rs:171-210
-    __device__ void finalize_logup(int batch) {
-        int n_batches = (n_fracs + batch - 1) / batch;
+    // data_structures.rs:171-210: NF fractions in batches of BATCH
+    template <int NF, int BATCH> __device__ __forceinline__ void finalize_logup() {
+        constexpr int NB = (NF + BATCH - 1) / BATCH;
         QM31 prev = q_zero();
-        for (int bi = 0; bi < n_batches; bi++) {
-            int lo = bi * batch, hi = lo + batch < n_fracs ? lo + batch : n_fracs;
+#pragma unroll
+        for (int bi = 0; bi < NB; bi++) {
+            const int lo = bi * BATCH, hi = lo + BATCH < NF ? lo + BATCH : NF;
             QM31 pp = fp[lo], qq = fq[lo];
+#pragma unroll
             for (int k = lo + 1; k < hi; k++) {
                 pp = q_add(q_mul(pp, fq[k]), q_mul(fp[k], qq));
                 qq = q_mul(qq, fq[k]);
             }
-            if (bi < n_batches - 1) {
+            if (bi < NB - 1) {
                 QM31 cur = q_combine_ef(smp(inter), smp(inter + 1), smp(inter + 2), smp(inter + 3));
                 inter += 4;
                 constraint(q_sub(q_mul(q_sub(cur, prev), qq), pp));
@@ -82,34 +84,18 @@ __device__ __noinline__ void q_internal(QM31* s) {
     for (int i = 1; i < 16; i++) s[i] = q_add(q_mul_m(s[i], 1u << (i + 1)), sum);
 }
 
-__global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                                             uint32_t n, const ProofMeta* __restrict__ metas,
-                                             ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
-                                             uint32_t n_pi) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const ProofMeta& m = metas[p];
-    if (m.reason != R_OK) return;
-    ProofCtx& c = ctxs[p];
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
-    uint32_t flags = 0;
-    QM31 z = ldq(c.z), alpha = ldq(c.alpha), plonk_sum = ldq(w + W_PLONK_SUM), poseidon_sum = ldq(w + W_POSEIDON_SUM);
-    {  // fiat_shamir/src/lib.rs:133-141
-        QM31 sum = q_zero();
-        for (uint32_t i = 0; i < n_pi; i++) {
-            QM31 dnm = q_sub(q_add(ldq(pi[i].value), q_mul_m(alpha, pi[i].idx % P)), z);
-            sum = q_add(sum, q_inv(dnm));
-        }
-        if (!q_eq(q_add(q_add(sum, poseidon_sum), plonk_sum), q_zero())) flags |= 1u << R_LOGUP;
-    }
+// The 86-constraint accumulator and the value it must equal (composition/src/lib.rs:60-120) for one proof whose
+// sampled values sit at their fixed word offsets behind `w`.  Shared by k_oods and by the probe k_oods_probe
+// (rsv_oods_eval), so that the evaluation can be checked on its own, on arbitrary samples.
+__device__ __noinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum, QM31 z,
+                                 QM31 alpha, QM31 rc, QM31 ox, QM31& acc_out, QM31& expected_out) {
     EvalCtx e;
-    e.rc = ldq(c.rc); e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
-    QM31 ox = ldq(c.oods_x);
+    e.rc = rc; e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
     const QM31 one = q_one();
     {  // plonk.rs:8-82 — preprocessed samples 0..10, trace samples 50..62, interaction samples 110..122
-        e.dinv = q_inv(q_double_x(ox, m.lp - 1));  // coset_vanishing: composition/src/lib.rs:18-29
-        e.shift = q_mul_m(plonk_sum, m_inv(1u << m.lp));  // data_structures.rs:67-68
-        e.inter = S_T2; e.n_fracs = 0;
+        e.dinv = q_inv(q_double_x(ox, lp - 1));  // coset_vanishing: composition/src/lib.rs:18-29
+        e.shift = q_mul_m(plonk_sum, m_inv(1u << lp));  // data_structures.rs:67-68
+        e.inter = S_T2;
         const int pre = S_T0, tr = S_T1;
         QM31 enforce = e.smp(pre + 9), op = e.smp(pre + 3);
         e.constraint(q_mul(enforce, e.smp(tr + 9)));
@@ -119,16 +105,16 @@ __global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, c
         QM31 b = q_combine_ef(e.smp(tr + 4), e.smp(tr + 5), e.smp(tr + 6), e.smp(tr + 7));
         QM31 cc = q_combine_ef(e.smp(tr + 8), e.smp(tr + 9), e.smp(tr + 10), e.smp(tr + 11));
         e.constraint(q_sub(q_sub(cc, q_mul(op, q_add(a, b))), q_mul(q_mul(q_sub(one, op), a), b)));
-        e.relation(e.smp(pre + 4), a, e.smp(pre + 0));
-        e.relation(e.smp(pre + 5), b, e.smp(pre + 1));
-        e.relation(e.smp(pre + 6), cc, e.smp(pre + 2));
-        e.relation(q_neg(e.smp(pre + 8)), e.smp(pre + 7), a, b);
-        e.finalize_logup(2);
+        e.relation<0>(e.smp(pre + 4), a, e.smp(pre + 0));
+        e.relation<1>(e.smp(pre + 5), b, e.smp(pre + 1));
+        e.relation<2>(e.smp(pre + 6), cc, e.smp(pre + 2));
+        e.relation<3>(q_neg(e.smp(pre + 8)), e.smp(pre + 7), a, b);
+        e.finalize_logup<4, 2>();
     }
     {  // poseidon.rs:73-241 — preprocessed 10..50, trace 62..110, interaction samples 122..134
-        e.dinv = q_inv(q_double_x(ox, m.lq - 1));
-        e.shift = q_mul_m(poseidon_sum, m_inv(1u << m.lq));
-        e.inter = S_T2 + 12; e.n_fracs = 0;
+        e.dinv = q_inv(q_double_x(ox, lq - 1));
+        e.shift = q_mul_m(poseidon_sum, m_inv(1u << lq));
+        e.inter = S_T2 + 12;
         const int pre = S_T0 + 10, in = S_T1 + 12, mid = in + 16, out = in + 32;
         const int rc0 = pre + 4, rc1 = pre + 20;
         QM31 is_first = e.smp(pre), is_last = e.smp(pre + 1), is_full = e.smp(pre + 2), round_id = e.smp(pre + 3);
@@ -166,26 +152,262 @@ __global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, c
         QM31 in_left = q_dbl(round_id), in_right = q_add(in_left, one), out_left = q_add(in_right, one),
              out_right = q_add(out_left, one);
 #define EF4(base) q_combine_ef(e.smp(base), e.smp((base) + 1), e.smp((base) + 2), e.smp((base) + 3))
-        e.relation(q_sub(q_mul(ext1_nz, is_first), not_first), q_add(q_mul(is_first, ext1), q_mul(not_first, in_left)),
+        e.relation<0>(q_sub(q_mul(ext1_nz, is_first), not_first), q_add(q_mul(is_first, ext1), q_mul(not_first, in_left)),
                    EF4(in), EF4(in + 4));
-        e.relation(q_sub(q_mul(ext2_nz, is_first), not_first), q_add(q_mul(is_first, ext2), q_mul(not_first, in_right)),
+        e.relation<1>(q_sub(q_mul(ext2_nz, is_first), not_first), q_add(q_mul(is_first, ext2), q_mul(not_first, in_right)),
                    EF4(in + 8), EF4(in + 12));
-        e.relation(q_add(q_mul(ext1_nz, is_last), not_last), q_add(q_mul(is_last, ext1), q_mul(not_last, out_left)),
+        e.relation<2>(q_add(q_mul(ext1_nz, is_last), not_last), q_add(q_mul(is_last, ext1), q_mul(not_last, out_left)),
                    EF4(out), EF4(out + 4));
-        e.relation(q_add(q_mul(ext2_nz, is_last), not_last), q_add(q_mul(is_last, ext2), q_mul(not_last, out_right)),
+        e.relation<3>(q_add(q_mul(ext2_nz, is_last), not_last), q_add(q_mul(is_last, ext2), q_mul(not_last, out_right)),
                    EF4(out + 8), EF4(out + 12));
 #undef EF4
-        e.relation(q_mul(is_first, not_last), swap_val, e.smp(rc0));
-        e.finalize_logup(3);
+        e.relation<4>(q_mul(is_first, not_last), swap_val, e.smp(rc0));
+        e.finalize_logup<5, 3>();
     }
     {  // composition/src/lib.rs:106-120
         QM31 left = q_combine_ef(e.smp(S_T3), e.smp(S_T3 + 1), e.smp(S_T3 + 2), e.smp(S_T3 + 3));
         QM31 right = q_combine_ef(e.smp(S_T3 + 4), e.smp(S_T3 + 5), e.smp(S_T3 + 6), e.smp(S_T3 + 7));
-        uint32_t bound = umax(m.lp + 2, m.lq + 3);
-        QM31 expected = q_add(left, q_mul(right, q_double_x(ox, bound - 2)));
-        if (!q_eq(e.acc, expected)) flags |= 1u << R_COMPOSITION;
+        uint32_t bound = umax(lp + 2, lq + 3);
+        expected_out = q_add(left, q_mul(right, q_double_x(ox, bound - 2)));
     }
+    acc_out = e.acc;
+}
+
+// ------------------------------------------------------------------ row form
+// The same evaluation with ONE PROOF PER 16-LANE ROW (lane i = state word i of the Poseidon AIR's round function),
+// for batches too small to fill the machine with one lane per proof: there k_oods' ~880 dependent QM31
+// multiplications are pure latency on the critical path (transcript -> OODS -> verdict).  Here the 78 per-word
+// constraints of the Poseidon component are evaluated 16 at a time; the random-coefficient accumulation
+//     acc = sum_k c_k * dinv_k * rc^(85-k)            (data_structures.rs:26-28: acc = acc*rc + c*dinv, 86 times)
+// is regrouped so that lane i scales its own constraints by rc^(15-i) times a per-group power, and the lanes'
+// shares are added with a row all-reduce.  The external / internal matrices act coordinate-wise on QM31, so they are
+// the DPP forms of poseidon2_row.hpp applied to each of the 4 coordinates.  ~5x shorter latency, ~3x more issue slots
+// per proof than the lane form: the host picks by batch size (RSV_OODS=row|lane overrides, for tests).
+__device__ __forceinline__ QM31 q_mds_row(QM31 x, bool odd) {
+    return q_mk(mds_row(x.a.a, odd), mds_row(x.a.b, odd), mds_row(x.b.a, odd), mds_row(x.b.b, odd));
+}
+__device__ __forceinline__ QM31 q_sum_row(QM31 x) {
+    return q_mk(sum_row(x.a.a), sum_row(x.a.b), sum_row(x.b.a), sum_row(x.b.b));
+}
+__device__ __forceinline__ QM31 q_sel(bool c, QM31 a, QM31 b) {
+    return q_mk(c ? a.a.a : b.a.a, c ? a.a.b : b.a.b, c ? a.b.a : b.b.a, c ? a.b.b : b.b.b);
+}
+
+// Every lane of the row must be active.  The results are the same on all 16 lanes.
+__device__ __noinline__ void oods_eval_row(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum,
+                                           QM31 z, QM31 alpha, QM31 rc, QM31 ox, uint32_t i, QM31& acc_out,
+                                           QM31& expected_out) {
+    const QM31 one = q_one();
+    const bool odd = i & 1u;
+    auto smp = [&](int k) { return ldq(w + SAMPLES.off[k]); };
+    // pi^k(oods.x) for k = lp-1, lq-1 and bound-2 = max(lp, lq+1) from ONE doubling chain; both inverses from one
+    const uint32_t kb = umax(lp, lq + 1u);
+    QM31 vp = ox, vq = ox, vb = ox, cur = ox;
+#pragma unroll 1
+    for (uint32_t k = 1; k <= kb; k++) {
+        cur = q_sub(q_dbl(q_mul(cur, cur)), one);
+        if (k == lp - 1u) vp = cur;
+        if (k == lq - 1u) vq = cur;
+        if (k == kb) vb = cur;
+    }
+    QM31 dinv_p, dinv_q;
+    {
+        QM31 ti = q_inv(q_mul(vp, vq));
+        dinv_p = q_mul(ti, vq);
+        dinv_q = q_mul(ti, vp);
+    }
+    // ---- plonk component (6 constraints): sequential, identical on every lane
+    EvalCtx e;
+    e.rc = rc; e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
+    {
+        e.dinv = dinv_p;
+        e.shift = q_mul_m(plonk_sum, m_inv(1u << lp));
+        e.inter = S_T2;
+        const int pre = S_T0, tr = S_T1;
+        QM31 enforce = e.smp(pre + 9), op = e.smp(pre + 3);
+        e.constraint(q_mul(enforce, e.smp(tr + 9)));
+        e.constraint(q_mul(enforce, e.smp(tr + 10)));
+        e.constraint(q_mul(enforce, e.smp(tr + 11)));
+        QM31 a = q_combine_ef(e.smp(tr + 0), e.smp(tr + 1), e.smp(tr + 2), e.smp(tr + 3));
+        QM31 b = q_combine_ef(e.smp(tr + 4), e.smp(tr + 5), e.smp(tr + 6), e.smp(tr + 7));
+        QM31 cc = q_combine_ef(e.smp(tr + 8), e.smp(tr + 9), e.smp(tr + 10), e.smp(tr + 11));
+        e.constraint(q_sub(q_sub(cc, q_mul(op, q_add(a, b))), q_mul(q_mul(q_sub(one, op), a), b)));
+        e.relation<0>(e.smp(pre + 4), a, e.smp(pre + 0));
+        e.relation<1>(e.smp(pre + 5), b, e.smp(pre + 1));
+        e.relation<2>(e.smp(pre + 6), cc, e.smp(pre + 2));
+        e.relation<3>(q_neg(e.smp(pre + 8)), e.smp(pre + 7), a, b);
+        e.finalize_logup<4, 2>();
+    }
+    const QM31 acc_plonk = e.acc;
+    // ---- poseidon component: 78 per-word constraints on the lanes + 2 logup constraints
+    const int pre = S_T0 + 10, in = S_T1 + 12, mid = in + 16, out = in + 32;
+    const int rc0 = pre + 4, rc1 = pre + 20;
+    const QM31 is_first = smp(pre), is_last = smp(pre + 1), is_full = smp(pre + 2), round_id = smp(pre + 3);
+    const QM31 not_first = q_sub(one, is_first), not_last = q_sub(one, is_last), is_partial = q_sub(not_first, is_full);
+    const QM31 swap_val = smp(mid), one_minus_swap = q_sub(one, swap_val);
+    const QM31 in_i = smp(in + (int)i), mid_i = smp(mid + (int)i), out_i = smp(out + (int)i);
+    // powers of the random coefficient: lane i scales by rc^(15-i), a group by rc^{64,48,32,16,2}
+    const QM31 r2 = q_mul(rc, rc), r4 = q_mul(r2, r2), r8 = q_mul(r4, r4), r16 = q_mul(r8, r8), r32 = q_mul(r16, r16),
+               r64 = q_mul(r32, r32), r48 = q_mul(r32, r16), r80 = q_mul(r64, r16);
+    QM31 ri;
+    {
+        const uint32_t ex = 15u - i;
+        ri = q_sel(ex & 1u, rc, one);
+        ri = q_mul(ri, q_sel(ex & 2u, r2, one));
+        ri = q_mul(ri, q_sel(ex & 4u, r4, one));
+        ri = q_mul(ri, q_sel(ex & 8u, r8, one));
+    }
+    QM31 share;  // sum over this lane's constraints of c * rc^(group power), before the common rc^(15-i)
+    {   // first round: swap-mix of the two halves, external matrix (poseidon.rs:122-140)
+        const QM31 lo = smp(in + (int)(i & 7u)), hi = smp(in + (int)(i & 7u) + 8);
+        QM31 st = i < 8 ? q_add(q_mul(lo, one_minus_swap), q_mul(hi, swap_val))
+                        : q_add(q_mul(lo, swap_val), q_mul(hi, one_minus_swap));
+        st = q_mds_row(st, odd);
+        share = q_mul(q_mul(is_first, q_sub(st, out_i)), r64);
+    }
+    {   // full rounds (poseidon.rs:142-170)
+        const QM31 full = q_pow5(q_add(in_i, smp(rc0 + (int)i)));
+        share = q_add(share, q_mul(q_mul(is_full, q_sub(mid_i, full)), r48));
+        QM31 st = q_mds_row(mid_i, odd);
+        st = q_pow5(q_add(st, smp(rc1 + (int)i)));
+        st = q_mds_row(st, odd);
+        share = q_add(share, q_mul(q_mul(is_full, q_sub(out_i, st)), r32));
+    }
+    {   // partial rounds (poseidon.rs:172-196).  The chain continues from the SAMPLED mid value of each round, so the
+        // 14 S-boxes do not depend on each other: word 0 before round r is known to every lane (3*mid[r-1] + row sum),
+        // lane r keeps it and raises it to the fifth power afterwards, all 14 at once.
+        QM31 st = in_i, st0 = smp(in), mine = q_zero();
+#pragma unroll 1
+        for (int r = 0; r < 14; r++) {
+            mine = q_sel(i == (uint32_t)r, st0, mine);
+            const QM31 mr = smp(mid + r);
+            st = q_sel(i == 0u, mr, st);
+            const QM31 sum = q_sum_row(st);
+            const uint32_t dg = i == 0u ? 3u : (1u << (i + 1u));
+            st = q_add(sum, q_mul_m(st, dg));
+            st0 = q_add(sum, q_mul_m(mr, 3u));
+        }
+        const int rr = (int)(i < 14u ? i : 13u);
+        const QM31 v = q_pow5(q_add(mine, smp(rc0 + rr)));
+        QM31 cm = q_mul(is_partial, q_sub(smp(mid + rr), v));
+        cm = q_sel(i < 14u, cm, q_zero());
+        share = q_add(share, q_mul(cm, r16));
+        share = q_add(share, q_mul(q_mul(is_partial, q_sub(out_i, st)), r2));
+    }
+    const QM31 lanes = q_sum_row(q_mul(share, ri));
+    // logup of the poseidon component (poseidon.rs:198-239): c_78 * rc + c_79, identical on every lane
+    EvalCtx g;
+    g.rc = rc; g.acc = q_zero(); g.z = z; g.alpha = alpha; g.alpha2 = e.alpha2; g.w = w; g.dinv = one;
+    g.shift = q_mul_m(poseidon_sum, m_inv(1u << lq));
+    g.inter = S_T2 + 12;
+    {
+        QM31 ext1 = smp(pre + 36), ext2 = smp(pre + 37), ext1_nz = smp(pre + 38), ext2_nz = smp(pre + 39);
+        QM31 in_left = q_dbl(round_id), in_right = q_add(in_left, one), out_left = q_add(in_right, one),
+             out_right = q_add(out_left, one);
+#define EF4(base) q_combine_ef(smp(base), smp((base) + 1), smp((base) + 2), smp((base) + 3))
+        g.relation<0>(q_sub(q_mul(ext1_nz, is_first), not_first), q_add(q_mul(is_first, ext1), q_mul(not_first, in_left)),
+                   EF4(in), EF4(in + 4));
+        g.relation<1>(q_sub(q_mul(ext2_nz, is_first), not_first), q_add(q_mul(is_first, ext2), q_mul(not_first, in_right)),
+                   EF4(in + 8), EF4(in + 12));
+        g.relation<2>(q_add(q_mul(ext1_nz, is_last), not_last), q_add(q_mul(is_last, ext1), q_mul(not_last, out_left)),
+                   EF4(out), EF4(out + 4));
+        g.relation<3>(q_add(q_mul(ext2_nz, is_last), not_last), q_add(q_mul(is_last, ext2), q_mul(not_last, out_right)),
+                   EF4(out + 8), EF4(out + 12));
+#undef EF4
+        g.relation<4>(q_mul(is_first, not_last), swap_val, smp(rc0));
+        g.finalize_logup<5, 3>();
+    }
+    acc_out = q_add(q_mul(acc_plonk, r80), q_mul(dinv_q, q_add(lanes, g.acc)));
+    {   // composition/src/lib.rs:106-120
+        QM31 left = q_combine_ef(smp(S_T3), smp(S_T3 + 1), smp(S_T3 + 2), smp(S_T3 + 3));
+        QM31 right = q_combine_ef(smp(S_T3 + 4), smp(S_T3 + 5), smp(S_T3 + 6), smp(S_T3 + 7));
+        expected_out = q_add(left, q_mul(right, vb));
+    }
+}
+
+__global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                             uint32_t n, const ProofMeta* __restrict__ metas,
+                                             ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
+                                             uint32_t n_pi) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    uint32_t flags = 0;
+    QM31 z = ldq(c.z), alpha = ldq(c.alpha), plonk_sum = ldq(w + W_PLONK_SUM), poseidon_sum = ldq(w + W_POSEIDON_SUM);
+    {  // fiat_shamir/src/lib.rs:133-141
+        QM31 sum = q_zero();
+        for (uint32_t i = 0; i < n_pi; i++) {
+            QM31 dnm = q_sub(q_add(ldq(pi[i].value), q_mul_m(alpha, pi[i].idx % P)), z);
+            sum = q_add(sum, q_inv(dnm));
+        }
+        if (!q_eq(q_add(q_add(sum, poseidon_sum), plonk_sum), q_zero())) flags |= 1u << R_LOGUP;
+    }
+    QM31 acc, expected;
+    oods_eval(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), acc, expected);
+    if (!q_eq(acc, expected)) flags |= 1u << R_COMPOSITION;
     if (flags) atomicOr(&c.flags, flags);
+}
+
+// Row-form pipeline kernel: 16 lanes per proof; whole rows leave together (DPP needs every lane of a live row).
+__global__ __launch_bounds__(256) void k_oods_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                  uint32_t n, const ProofMeta* __restrict__ metas,
+                                                  ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
+                                                  uint32_t n_pi) {
+    const uint32_t i = threadIdx.x & 15u;
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (p >= n) return;
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    uint32_t flags = 0;
+    QM31 z = ldq(c.z), alpha = ldq(c.alpha), plonk_sum = ldq(w + W_PLONK_SUM), poseidon_sum = ldq(w + W_POSEIDON_SUM);
+    {  // fiat_shamir/src/lib.rs:133-141: the public inputs are dealt to the lanes, their fractions added over the row
+        QM31 sum = q_zero();
+        for (uint32_t k = i; k < n_pi; k += 16u) {
+            QM31 dnm = q_sub(q_add(ldq(pi[k].value), q_mul_m(alpha, pi[k].idx % P)), z);
+            sum = q_add(sum, q_inv(dnm));
+        }
+        sum = q_sum_row(sum);
+        if (!q_eq(q_add(q_add(sum, poseidon_sum), plonk_sum), q_zero())) flags |= 1u << R_LOGUP;
+    }
+    QM31 acc, expected;
+    oods_eval_row(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), i, acc, expected);
+    if (!q_eq(acc, expected)) flags |= 1u << R_COMPOSITION;
+    if (flags && i == 0) atomicOr(&c.flags, flags);
+}
+
+__global__ __launch_bounds__(256) void k_oods_row_probe(const uint32_t* __restrict__ prefix, uint32_t prefix_words,
+                                                        const uint32_t* __restrict__ params, uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t i = threadIdx.x & 15u;
+    const uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (it >= n) return;
+    const uint32_t* pr = params + (size_t)it * 26;
+    QM31 acc, expected;
+    oods_eval_row(prefix + (size_t)it * prefix_words, pr[0], pr[1], ldq(pr + 2), ldq(pr + 6), ldq(pr + 10), ldq(pr + 14),
+                  ldq(pr + 18), ldq(pr + 22), i, acc, expected);
+    if (i == 5) {  // any lane: the results are row-uniform
+        stq(out + (size_t)it * 8, acc);
+        stq(out + (size_t)it * 8 + 4, expected);
+    }
+}
+
+// Probe (rsv_oods_eval): item i = a proof prefix of OODS_PREFIX_WORDS words (only the sampled values are read) plus
+// 26 parameter words lp, lq, plonk_sum, poseidon_sum, z, alpha, random_coeff, oods.x; out = accumulator | expected.
+constexpr uint32_t OODS_PARAM_WORDS = 26;
+__global__ __launch_bounds__(64) void k_oods_probe(const uint32_t* __restrict__ prefix, uint32_t prefix_words,
+                                                   const uint32_t* __restrict__ params, uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* pr = params + (size_t)i * OODS_PARAM_WORDS;
+    QM31 acc, expected;
+    oods_eval(prefix + (size_t)i * prefix_words, pr[0], pr[1], ldq(pr + 2), ldq(pr + 6), ldq(pr + 10), ldq(pr + 14), ldq(pr + 18),
+              ldq(pr + 22), acc, expected);
+    stq(out + (size_t)i * 8, acc);
+    stq(out + (size_t)i * 8 + 4, expected);
 }
 
 }  // namespace rsv

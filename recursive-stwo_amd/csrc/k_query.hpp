@@ -21,6 +21,11 @@ struct QueryArgs {
     uint32_t* leafv;  // [n][3 + maxInner][G][8]
     uint32_t maxInner;
     uint32_t* folded_out;  // optional [n][3][G][4]: first-layer folds per size group, transcript query order
+    // optional value dump (rsv_hints_out::d_query_values), [n][G][qv_stride] in transcript query order, per query:
+    //   answers[3] | first-layer folds[3] | value entering inner layer i, i < maxInner | value entering the last-layer
+    //   check | the last-layer polynomial evaluated at the query's point      (QM31 each; absent groups stay zero)
+    uint32_t* qv_out;
+    uint32_t qv_stride;
 };
 
 __device__ __forceinline__ uint32_t ent_rb(uint32_t e) { return e & 0xFFu; }
@@ -70,6 +75,9 @@ __device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n
     return acc;
 }
 
+// folding/src/lib.rs:194-204: the folded value of a query must equal the last-layer polynomial at its point
+__device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q_eq(eval, folded); }
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     __shared__ uint32_t xq[BLOCK][4];
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     uint32_t flags = 0;
     uint32_t M = live ? m->M : 0, A = live ? m->A : 0, B = live ? m->B : 0;
     uint32_t qj = live ? c->q[j] : 0;
+    uint32_t* qv = (live && a.qv_out) ? a.qv_out + ((size_t)slot * G + c->qperm[j]) * a.qv_stride : nullptr;
     uint32_t n_sizes = live ? c->n_sizes : 0;
     QM31 first[3];
     // Domain points.  One scalar multiplication gives the point of the query at level M; the points at the
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
             uint32_t by = (pos & 1u) ? m_neg(dp[g].y) : dp[g].y;
             first[g] = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
             if (a.folded_out) stq(a.folded_out + (((size_t)slot * 3 + g) * G + c->qperm[j]) * 4, first[g]);
+            if (qv) { stq(qv + 4 * g, answer); stq(qv + 12 + 4 * g, first[g]); }
         }
         __syncthreads();
     }
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
             if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= 1u << R_FRI_INNER;  // hints/src/folding.rs:558
             uint32_t* lv = leafv + ((size_t)(3 + i) * G + j) * 8;
             stq(lv, folded); stq(lv + 4, sib);
+            if (qv) stq(qv + 24 + 4 * i, folded);
             uint32_t xr = (i == 0) ? X : m_sub(m_dbl(m_sqr(X)), 1u);
             X = (pos & 1u) ? m_neg(xr) : xr;
             folded = fold_pair(folded, sib, pos & 1u, m_inv(X), ldq(c->fri_alpha[i + 1]));
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
     if (live) {
         // x of half_odds(l-1).at(bit_reverse(pos >> 1)) = pi(X_l) (for a proof without inner layers: pi of x_M)
         QM31 acc = line_eval(w + m->last_off, m->log_last, m->last_n, m_sub(m_dbl(m_sqr(X)), 1u));
-        if (!q_eq(acc, folded)) flags |= 1u << R_FRI_LAST;
+        if (!last_layer_ok(acc, folded)) flags |= 1u << R_FRI_LAST;
+        if (qv) { stq(qv + 24 + 4 * a.maxInner, folded); stq(qv + 28 + 4 * a.maxInner, acc); }
     }
     if (flags) atomicOr(&c->flags, flags);
 }
@@ -263,6 +275,16 @@ __global__ __launch_bounds__(256) void k_domain_points(uint32_t log_size, const 
     if (i >= n) return;
     CPoint p = domain_point(log_size, q[i] & ((1u << log_size) - 1u));
     xy[2 * i] = p.x; xy[2 * i + 1] = p.y;
+}
+
+// rsv_last_layer_check: the comparison k_query raises RSV_R_FRI_LAST from, on its own: ok[i] = 1 iff the polynomial
+// evaluated at x[i] equals folded[i].
+__global__ __launch_bounds__(256) void k_last_layer_check(const uint32_t* __restrict__ coeffs, uint32_t log_n,
+                                                           const uint32_t* __restrict__ x, const uint32_t* __restrict__ folded,
+                                                           uint8_t* __restrict__ ok, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ok[i] = last_layer_ok(line_eval(coeffs, log_n, 1u << log_n, x[i]), ldq(folded + 4 * i)) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_line_eval(const uint32_t* __restrict__ coeffs, uint32_t log_n,

@@ -31,7 +31,8 @@ class Cfg:
         return f"Cfg(pow={self.pow_bits}, blowup={self.log_blowup_factor}, last={self.log_last_layer_degree_bound}, nq={self.n_queries})"
 
 
-_DERIVED = {"small_proof_composition.bin": "small_proof.bin", "small_proof_dup_query.bin": "small_proof.bin"}
+_DERIVED = {"small_proof_composition.bin": "small_proof.bin", "small_proof_dup_query.bin": "small_proof.bin",
+            "recursive_proof_16_15_composition.bin": "recursive_proof_16_15.bin", "level1-5_dup_query.bin": "level1-5.bin"}
 
 
 def fixture_cfg(name):

@@ -335,6 +335,48 @@ def fri_paths(proof: bytes, n_queries: int, max_log: int, n_trees: int, inputs=S
     return sib, cols
 
 
+def oods_eval(samples, params):
+    sm = _u32(samples).reshape(-1, 142, 4)
+    pr = _u32(params).reshape(-1, 26)
+    out = np.empty((sm.shape[0], 8), np.uint32)
+    lib.rsvo_oods_eval.restype = ctypes.c_int
+    lib.rsvo_oods_eval.argtypes = [_u32p, _u32p, _u32p, sz]
+    rc = lib.rsvo_oods_eval(sm.ctypes.data_as(_u32p), pr.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p), sm.shape[0])
+    assert rc == 0, rc
+    return out
+
+
+def query_dump(proof: bytes, inputs=STANDARD_INPUTS):
+    """-> uint32[nq, 4 * (8 + n_inner)]: the layout of rsv_hints_out::d_query_values for one proof."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    out = np.zeros(128 * 4 * (8 + 29), np.uint32)
+    ni, nq = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    pi = make_inputs(inputs)
+    lib.rsvo_query_dump.restype = ctypes.c_int
+    lib.rsvo_query_dump.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, _u32p, _u32p]
+    rc = lib.rsvo_query_dump(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), out.ctypes.data_as(_u32p), out.size,
+                             ni.ctypes.data_as(_u32p), nq.ctypes.data_as(_u32p))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_query_dump -> {rc}")
+    stride = 4 * (8 + int(ni[0]))
+    return out[:int(nq[0]) * stride].reshape(int(nq[0]), stride).copy()
+
+
+def sampled_values(proof: bytes) -> np.ndarray:
+    """The 142 sampled values of a proof, flattened tree-major / column-major / sample-minor: uint32[142, 4]."""
+    w = np.frombuffer(proof, dtype=np.uint32)
+    pos, out = 49 + 2, []
+    for t, ncols in enumerate((50, 60, 16, 8)):
+        assert int(w[pos]) == ncols
+        pos += 2
+        for c in range(ncols):
+            ns = int(w[pos]); pos += 2
+            for _ in range(ns):
+                out.append(w[pos:pos + 4].copy()); pos += 4
+    assert pos == 895 and len(out) == 142
+    return np.stack(out)
+
+
 def proof_layout(proof: bytes):
     """Word offsets of the variable part of a proof: FRI layer commitments and the position of
     every u64 length prefix (`prefixes`: (word offset, count, what))."""

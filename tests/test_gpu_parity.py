@@ -686,6 +686,51 @@ def test_reject_fixtures_behind_the_proof_of_work(rsv):
     assert reason.tolist() == oreason.tolist() == [4, 0, 5] * 3
 
 
+def test_big_shape_reject_fixtures_behind_the_proof_of_work(rsv, monkeypatch):
+    """RSV_R_COMPOSITION on a 2^16 / 2^15 proof and RSV_R_DUP_QUERY on the 80-query shape (re-ground fixtures), in
+    one mixed batch with genuine proofs around them, under both OODS kernels and both plan kernels."""
+    names = ["recursive_proof_16_15_composition.bin", "recursive_proof_16_15.bin", "level1-5_dup_query.bin", "level1-5.bin",
+             "recursive_proof_16_15_composition.bin", "level13-1.bin"]
+    batch = [read_proof(x) for x in names]
+    cfgs = [fixture_cfg(x) for x in names]
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert oacc.tolist() == [0, 1, 0, 1, 0, 1] and oreason.tolist() == [4, 0, 5, 0, 4, 0]
+    for oods in ("row", "lane"):
+        for plan in ("serial", "parallel"):
+            monkeypatch.setenv("RSV_OODS", oods)
+            monkeypatch.setenv("RSV_PLAN", plan)
+            acc, reason = rsv.verify_batch(batch, cfgs)
+            assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), (oods, plan)
+
+
+@pytest.mark.parametrize("mode", ["row", "lane"])
+def test_oods_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+    """Both OODS kernels (one proof per 16-lane DPP row / one proof per lane): the probe on random samples and the
+    whole pipeline on fixtures, wrong public inputs (logup) and the composition reject fixtures."""
+    monkeypatch.setenv("RSV_OODS", mode)
+    rng = np.random.default_rng(55)
+    n = 200
+    sm = rng.integers(0, P, (n, 142, 4), dtype=np.uint32)
+    pr = rng.integers(0, P, (n, 26), dtype=np.uint32)
+    pr[:, 0], pr[:, 1] = rng.integers(1, 27, n), rng.integers(1, 27, n)
+    pr[:4, 0], pr[:4, 1] = [1, 28, 1, 28], [1, 1, 28, 28]
+    assert np.array_equal(rsv.oods_eval(sm, pr), ob.oods_eval(sm, pr))
+    std = [e for e in manifest if len(e["inputs"]) == 3 and e["expect"] == "ok"]
+    batch = [read_proof(e["file"]) for e in std] + [read_proof("recursive_proof_16_15_composition.bin")]
+    cfgs = [fixture_cfg(e["file"]) for e in std] + [fixture_cfg("recursive_proof_16_15.bin")]
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    assert acc.tolist() == [1] * len(std) + [0] and reason.tolist() == [0] * len(std) + [4]
+    # 19 public inputs (more than one per lane of a row), all but the genuine three cancelling in pairs is not possible:
+    # any extra input breaks the logup sum
+    wrong = list(rsv.STANDARD_INPUTS) + [(k, (k, 1, 0, 0)) for k in range(4, 20)]
+    acc, reason = rsv.verify_batch(batch[:3], cfgs[:3], wrong)
+    oacc, oreason = ob.verify_batch(batch[:3], cfgs[:3], wrong)
+    assert acc.tolist() == oacc.tolist() == [0, 0, 0] and reason.tolist() == oreason.tolist() == [3, 3, 3]
+    small = [read_proof("small_proof.bin"), read_proof("small_proof_composition.bin")]
+    acc, reason = rsv.verify_batch(small, fixture_cfg("small_proof.bin"), [(1, (1, 0, 0, 0))])
+    assert acc.tolist() == [1, 0] and reason.tolist() == [0, 4]
+
+
 def _debug_lib():
     import ctypes
     import torch  # noqa: F401  (one HIP runtime per process: torch's)
@@ -740,3 +785,94 @@ def test_plan_kernels_agree_on_synthetic_query_sets():
         ent = par[2].reshape(n, M + 1, G)[:, 1:, :nq]
         sib = (ent >> 16) & 0xFF
         assert ((sib == 0xFF) | (sib < nq)).all() and ((ent & 0xFF) < nq).all()
+
+
+# ---------------------------------------------------------------- rows a10 / a11 / a12 on their own
+def test_oods_eval_probe_matches_oracle(rsv, manifest):
+    """rsv_oods_eval (the device function k_oods is made of) against the oracle: every accepting fixture (accumulator
+    == expected, bit-identical to the oracle's pair), perturbed samples / challenges (both sides unequal, same values),
+    and 300 random sample sets with random log sizes."""
+    from tests.test_oracle import oods_params_of
+    sm, pr = [], []
+    for e in manifest:
+        if e["expect"] != "ok":
+            continue
+        proof = read_proof(e["file"])
+        s0, p0 = ob.sampled_values(proof), oods_params_of(proof)
+        sm.append(s0); pr.append(p0)
+        for k in (0, 57, 110, 133):
+            bad = s0.copy(); bad[k, 2] = (int(bad[k, 2]) + 5) % P
+            sm.append(bad); pr.append(p0)
+        for k in (10, 14, 18, 22):
+            badp = p0.copy(); badp[k] = (int(badp[k]) + 1) % P
+            sm.append(s0); pr.append(badp)
+    rng = np.random.default_rng(31)
+    for _ in range(300):
+        sm.append(rng.integers(0, P, (142, 4), dtype=np.uint32))
+        p = rng.integers(0, P, 26, dtype=np.uint32)
+        p[0], p[1] = rng.integers(1, 24), rng.integers(1, 24)
+        pr.append(p)
+    sm, pr = np.stack(sm), np.stack(pr)
+    got, want = rsv.oods_eval(sm, pr), ob.oods_eval(sm, pr)
+    assert np.array_equal(got, want)
+    n_fix = sum(1 for e in manifest if e["expect"] == "ok")
+    for i in range(n_fix):
+        base = 9 * i
+        assert got[base, :4].tolist() == got[base, 4:].tolist()
+        assert all(got[base + k, :4].tolist() != got[base + k, 4:].tolist() for k in range(1, 9))
+    with pytest.raises(rsv.RsvError):
+        rsv.oods_eval(np.full((1, 142, 4), P, np.uint32), pr[:1])
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level1-5.bin",
+                                  "level10-1.bin", "level13-1.bin"])
+def test_query_values_match_oracle(rsv, manifest, name):
+    """Rows a11 / a12 by VALUE (not only by verdict): the DEEP-quotient answers at every column log size, their
+    circle-to-line folds, the value entering every inner FRI layer, the value entering the last-layer check and the
+    last-layer evaluation, per query, from the verifying pass == the oracle's."""
+    import torch
+    entry = next(e for e in manifest if e["file"] == name)
+    proof = read_proof(name)
+    lay = ob.proof_layout(proof)
+    nq, n_inner = entry["n_queries"], lay["n_inner"]
+    M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
+    inputs = entry_inputs(entry)
+    want = ob.query_dump(proof, inputs)
+    n = 3
+    blob, offsets = rsv.pack([proof] * n)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_qv = torch.zeros((n, nq, 4 * (8 + n_inner)), dtype=torch.int32, device=dev)
+    ctx = rsv.Context(0)
+    ctx.verify_hints(d_blob, d_off, n, d_acc, None, cfg=fixture_cfg(name), inputs=inputs, shape=(nq, M, n_inner), d_query_values=d_qv)
+    ctx.synchronize()
+    assert d_acc.cpu().numpy().tolist() == [1] * n
+    got = d_qv.cpu().numpy().view(np.uint32)
+    for k in range(n):
+        assert np.array_equal(got[k], want), k
+    ni = n_inner
+    assert np.array_equal(got[0][:, 24 + 4 * ni:28 + 4 * ni], got[0][:, 28 + 4 * ni:32 + 4 * ni])  # accept side of RSV_R_FRI_LAST
+    ctx.close()
+
+
+def test_last_layer_check_probe(rsv):
+    """RSV_R_FRI_LAST both ways through the device function k_query raises it from: a mutated proof never reaches the
+    last-layer comparison (its polynomial is hashed before the proof of work), so the comparison is probed directly —
+    equal values pass, any single changed word of the folded value or of a coefficient fails."""
+    rng = np.random.default_rng(41)
+    for log_n in (0, 2, 7, 8):
+        coeffs = rng.integers(0, P, (1 << log_n, 4), dtype=np.uint32)
+        xs = rng.integers(0, P, 500, dtype=np.uint32)
+        good = ob.line_eval(coeffs, xs)
+        assert rsv.last_layer_check(coeffs, xs, good).tolist() == [1] * 500
+        bad = good.copy()
+        bad[np.arange(500), rng.integers(0, 4, 500)] ^= np.uint32(1)
+        bad %= np.uint32(P)
+        differs = (bad != good).any(axis=1)
+        assert rsv.last_layer_check(coeffs, xs, bad).tolist() == (~differs).astype(np.uint8).tolist() and differs.sum() > 480
+        c2 = coeffs.copy(); c2[-1, 3] = (int(c2[-1, 3]) + 1) % P
+        assert rsv.last_layer_check(c2, xs, good).sum() == 0  # the top coefficient weighs on every point (weights are products of x's: nonzero w.h.p.)
+    with pytest.raises(ValueError):
+        rsv.line_eval(np.zeros((3, 4), np.uint32), [1])  # not a power of two

@@ -459,3 +459,49 @@ def test_lowered_security_words_are_rejected():
     # no configuration at all is API misuse, not "trust the header"
     assert ob.lib.rsvo_verify_batch(blob.ctypes.data_as(ob._u8p), offsets.ctypes.data_as(ob._u64p), 2, None, pi, 1,
                                     acc.ctypes.data_as(ob._u8p), reason.ctypes.data_as(ob._u8p)) == -1
+
+
+def oods_params_of(proof):
+    """The 26 parameter words of rsv_oods_eval / rsvo_oods_eval for a genuine proof, from the oracle's transcript."""
+    w = np.frombuffer(proof, dtype=np.uint32)
+    t = ob.transcript_raw(proof)
+    return np.concatenate([w[0:2], w[2:10], t[4:8], t[8:12], t[12:16], t[20:24]]).astype(np.uint32)
+
+
+@pytest.mark.parametrize("entry", [e for e in load_manifest() if e["expect"] == "ok"], ids=lambda e: e["file"])
+def test_oods_eval_probe_on_fixtures(entry):
+    """Row a10 on its own: on every accepting fixture the 86-constraint accumulator equals the value of the committed
+    composition polynomial (that IS the reference's check, composition/src/lib.rs:106-120); one changed sample or
+    challenge breaks the equality."""
+    proof = read_proof(entry["file"])
+    sm, pr = ob.sampled_values(proof), oods_params_of(proof)
+    out = ob.oods_eval(sm[None], pr[None])[0]
+    assert out[:4].tolist() == out[4:].tolist() and any(out[:4])
+    for k in (0, 57, 110, 133):
+        bad = sm.copy(); bad[k, 1] = (int(bad[k, 1]) + 1) % 0x7FFFFFFF
+        o = ob.oods_eval(bad[None], pr[None])[0]
+        assert o[:4].tolist() != o[4:].tolist(), k
+    for k in (10, 14, 18, 22):  # z, alpha, random_coeff, oods.x
+        badp = pr.copy(); badp[k] = (int(badp[k]) + 1) % 0x7FFFFFFF
+        o = ob.oods_eval(sm[None], badp[None])[0]
+        assert o[:4].tolist() != o[4:].tolist(), k
+
+
+def test_query_dump_is_consistent_with_the_older_probes():
+    proof = read_proof("recursive_proof_16_15.bin")
+    d = ob.query_dump(proof)
+    ni = d.shape[1] // 4 - 8
+    assert np.array_equal(d[:, 12:24].reshape(16, 3, 4).transpose(1, 0, 2), ob.fri_folded(proof))
+    assert np.array_equal(d[:, 24 + 4 * ni:28 + 4 * ni], d[:, 28 + 4 * ni:32 + 4 * ni])  # folded == last-layer evaluation
+
+
+def test_big_shape_reject_fixtures_behind_the_proof_of_work():
+    """The same two rejection stages for big shapes (tests/golden/make_reject_fixtures.py big): a 2^16 / 2^15 proof with
+    one changed sampled value, and the 80-query level1-5 proof re-ground until two of its positions collide."""
+    comp, dup = read_proof("recursive_proof_16_15_composition.bin"), read_proof("level1-5_dup_query.bin")
+    acc, reason = ob.verify_batch([comp, read_proof("recursive_proof_16_15.bin"), dup, read_proof("level1-5.bin")],
+                                  [fixture_cfg("recursive_proof_16_15.bin")] * 2 + [fixture_cfg("level1-5.bin")] * 2)
+    assert acc.tolist() == [0, 1, 0, 1] and reason.tolist() == [4, 0, 5, 0]
+    t = ob.transcript_raw(dup)
+    q = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + 80] & ((1 << int(t[3])) - 1)
+    assert len(set(q.tolist())) < 80 and t[0] == 0
