@@ -140,19 +140,16 @@ def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
             "perms_per_proof": (sum(perms) / len(perms)) if perms else None}
 
 
-# Instruction-cost ceiling of the permutation on one MI355X (costs measured with tools/valu_lab.hip at
-# 4 waves/SIMD): per 64 permutations (one wave-level call of poseidon2()) the kernel issues ~1 660 slow-class
-# wave-instructions (v_mad_u64_u32 / v_lshl_add_u64, ~4.5 cycles each) and ~2 800 fast-class ones (~2.5 cycles);
-# 1 024 SIMDs at the sustained 2.37 GHz the Merkle kernels hold.  See tools/perm_ceiling.py for the census that
-# produces the two instruction counts from the shipped code object.
-PERM_SLOW_INSTS, PERM_FAST_INSTS = 1660, 2800
-PERM_SLOW_CYCLES, PERM_FAST_CYCLES = 4.5, 2.5
-SIMDS, SUSTAINED_GHZ = 1024, 2.37
+# Instruction-cost ceiling of the permutation on one MI355X: the dynamic VALU mix of one wave-level call of
+# rsv::poseidon2() (64 permutations) priced with the per-instruction issue costs measured by tools/valu_lab.hip at
+# 4 waves/SIMD.  Derivation, class table and the PMC cross-check: tools/perm_ceiling.py (same numbers) and DESIGN §4.
+PERM_MIX = [("fast", 2314, 2.50), ("v_min_u32", 442, 4.27), ("v_mad_u64_u32", 526, 4.54), ("v_lshl_add_u64", 410, 4.48),
+            ("v_mad_u64_u32+addend", 736, 5.10)]
+SIMDS, LAB_GHZ = 1024, 2.4
 
 
 def perm_ceiling_per_s():
-    cycles_per_wave_call = PERM_SLOW_INSTS * PERM_SLOW_CYCLES + PERM_FAST_INSTS * PERM_FAST_CYCLES
-    return SIMDS * SUSTAINED_GHZ * 1e9 / cycles_per_wave_call * 64.0
+    return SIMDS * LAB_GHZ * 1e9 / sum(n * c for _, n, c in PERM_MIX) * 64.0
 
 
 def main():
@@ -327,8 +324,9 @@ def main():
         valu = {"poseidon2_perms_per_s": perms_per_s, "perm_GBps": m * 128 / pdt / 1e9,
                 "perm_hbm_frac": m * 128 / pdt / 1e9 / HBM_PEAK_GBPS, "states": m,
                 "ceiling_perms_per_s": ceil, "frac_of_ceiling": perms_per_s / ceil,
-                "ceiling_model": f"{PERM_SLOW_INSTS} x {PERM_SLOW_CYCLES} + {PERM_FAST_INSTS} x {PERM_FAST_CYCLES} cycles per "
-                                 f"64 permutations, {SIMDS} SIMDs at {SUSTAINED_GHZ} GHz (DESIGN §4)"}
+                "ceiling_model": "sum over instruction classes of count x measured issue cost (tools/valu_lab.hip, 4 waves/SIMD) = "
+                                 f"{sum(n * c for _, n, c in PERM_MIX):.0f} cycles-at-2.4-GHz per 64 permutations per SIMD, {SIMDS} SIMDs "
+                                 "(tools/perm_ceiling.py, DESIGN §4)"}
         del d_in, d_out
 
     cpu = None

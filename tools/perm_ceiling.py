@@ -1,0 +1,54 @@
+"""Instruction-cost ceiling of the Poseidon2 permutation on one MI355X (bench.py: valu.ceiling_perms_per_s).
+
+Dynamic VALU instruction mix of ONE wave-level call of rsv::poseidon2() (64 permutations), derived from the source
+(recursive-stwo_amd/csrc/poseidon2.hpp) and checked against the hardware count:
+
+  S-box with its pre-reduction, x -> x^5 (142 of them: 8 full rounds x 16 + 14 partial rounds x 1)
+      fold2 (lshr, add) + canon (add-literal, min) + pow5 (2 x [add, mad, lshr, add, add-literal, min] + [mad, lshr, add])
+      = 13 fast, 3 v_min_u32, 3 v_mad_u64_u32 without addend            (the partial-round S-box has no fold2: 11 fast)
+  full-round linear layer mds16_2x (9 of them; the last one carries no round constants)
+      per 4-word group 2 mad (no addend) + 4 mad (addend) + 2 lshl_add_u64 + 2 lshl_add_u64 (plain adds)        = 40
+      column sums 12 + 16 lshl_add_u64, round constants 16 mad (addend)                                         = 44
+  partial round (14): 2 mad (no addend) + 14 + 1 + 1 + 15 mad (addend) + 1 lshl_add_u64, 16 fold2 = 32 fast
+  output: 16 x (lshr, add, add-literal, min)
+
+  class                      count   cycles/instr at 4 waves/SIMD, expressed at 2.4 GHz (tools/valu_lab.hip, measured r2)
+  fast  (add/sub/lshr/and)    2314   2.50
+  v_min_u32                    442   4.27
+  v_mad_u64_u32, no addend     526   4.54
+  v_lshl_add_u64               410   4.48
+  v_mad_u64_u32, with addend   736   5.10     (SGPR multiplier or live 64-bit addend: 5.05-5.15)
+  total                       4428            PMC: SQ_INSTS_VALU / wave of k_permute = 4510 incl. loads, stores, call
+
+=> 15 650 cycles-at-2.4-GHz per 64 permutations per SIMD => 1024 SIMDs x 2.4e9 / 15 650 x 64 = 10.05 G permutations/s.
+(The lab's "cycles at 2.4 GHz" are wall time x 2.4 GHz: whatever clock the chip really holds under an all-VALU load is
+already inside them, so the ceiling is a time, not a cycle, bound.)
+
+Usage: python tools/perm_ceiling.py [path/to/asm]   — with an assembly listing (hipcc -S --cuda-device-only) it also
+prints the STATIC opcode histogram of rsv::poseidon2 as a cross-check of the class membership."""
+import collections
+import re
+import sys
+
+MIX = [("fast", 2314, 2.50), ("v_min_u32", 442, 4.27), ("v_mad_u64_u32 (no addend)", 526, 4.54),
+       ("v_lshl_add_u64", 410, 4.48), ("v_mad_u64_u32 (addend)", 736, 5.10)]
+SIMDS, LAB_GHZ = 1024, 2.4
+
+
+def ceiling():
+    cycles = sum(n * c for _, n, c in MIX)
+    return SIMDS * LAB_GHZ * 1e9 / cycles * 64.0, cycles, sum(n for _, n, _ in MIX)
+
+
+def main():
+    perms, cycles, insts = ceiling()
+    print(f"{insts} VALU instructions, {cycles:.0f} cycles@2.4GHz per wave-level call -> ceiling {perms / 1e9:.2f} G permutations/s")
+    if len(sys.argv) > 1:
+        s = open(sys.argv[1]).read()
+        m = re.search(r"\n_ZN3rsv9poseidon2ENS_7State16E:.*?s_setpc_b64", s, re.S)
+        ops = collections.Counter(l.split()[0] for l in m.group(0).splitlines() if l.startswith("\t") and not l.strip().startswith((".", ";")))
+        print("static histogram of rsv::poseidon2 (loops counted once):", ops.most_common(12))
+
+
+if __name__ == "__main__":
+    main()

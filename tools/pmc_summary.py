@@ -1,7 +1,10 @@
 """gpurun_out/<tag>/ (tools/profile.sh) -> profiles/<tag>_{bench_n1_65536.json, bench_under_rocprof.json,
-kernel_stats_bench65536.csv, pmc_summary.csv}.  Usage: python tools/pmc_summary.py r1_final"""
+kernel_stats_bench65536.csv, pmc_summary.csv} and profiles/pmc_latest.json (what bench.py reads for roofline.traffic:
+keyed by a hash of the kernel sources that were profiled, so a stale profile is never quoted).
+Usage: python tools/pmc_summary.py r2_final"""
 import csv
 import glob
+import json
 import os
 import shutil
 import sys
@@ -30,7 +33,7 @@ def last_dispatch_counters(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r1_final"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r2_final"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(src, "bench_n1_65536.json"), os.path.join(dst, f"{tag}_bench_n1_65536.json"))
@@ -48,12 +51,18 @@ def main():
             counters.setdefault(k, {}).update(v)
     cols = ["kernel", "calls", "avg_ms", "FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_corrected", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
             "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "eff_clock_GHz", "valu_winst_per_s",
-            "valu_issue_frac_of_1.2288e12"]
+            "valu_issue_frac_of_1.2288e12", "wave_wait_any_frac", "wave_wait_issue_frac", "wave_active_frac",
+            "frac_of_perm_mix_issue_ceiling"]
+    latest = {"tag": tag, "proofs": 65536, "kernels": {},
+              "kernel_sources_sha": open(os.path.join(src, "kernel_sources_sha.txt")).read().strip()}
     with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
         f.write(f"# rocprofv3 summary, {tag} build — `python bench.py --steps 1..2 --warmup 1` (65 536 proofs, 7.71 GB, one MI355X); tools/profile.sh + tools/pmc_summary.py\n")
         f.write(f"# kernel-trace pass: profiles/{tag}_kernel_stats_bench65536.csv; counters from four separate --pmc passes (no trace domains mixed in)\n")
         f.write("# FETCH_SIZE / WRITE_SIZE are KiB as reported; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream, MI355X_MICROARCH.md)\n")
         f.write("# eff_clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / avg_ms; valu_issue_frac = SQ_INSTS_VALU / avg_ms against 1024 SIMDs x 2.4 GHz / 2 cycles\n")
+        f.write("# wave_*_frac: SQ_WAIT_ANY (parked at s_waitcnt / barrier), SQ_WAIT_INST_ANY (ready but not issued: the VALU is taken by another wave) and SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; they sum to ~1\n")
+        f.write("# frac_of_perm_mix_issue_ceiling = SQ_INSTS_VALU x 3.534 cycles-at-2.4-GHz (mean issue cost of the permutation's instruction mix, tools/perm_ceiling.py) / (avg_ms x 1024 SIMDs x 2.4 GHz): meaningful for the permutation-dominated kernels only\n")
+        f.write("# counter passes serialize the dispatches: per-kernel counters are those of the kernel running ALONE, avg_ms comes from the (concurrent) kernel-trace pass\n")
         f.write("# kernels on the side stream (k_row_hash, k_query, k_oods, k_qconst, k_scan) overlap main-stream kernels: their durations and clocks are not isolated\n")
         f.write(",".join(cols) + "\n")
         for k in sorted(avg_ms, key=lambda k: -avg_ms[k][1] * avg_ms[k][0]):
@@ -66,7 +75,16 @@ def main():
             f.write(",".join(str(x) for x in [k, calls, round(ms, 4), int(fetch), int(write), int((2 * fetch + write) * 1024),
                                               int(c.get("SQ_INSTS_VALU", 0)), int(c.get("SQ_INSTS_SALU", 0)), int(c.get("SQ_WAVES", 0)),
                                               int(c.get("SQ_WAVE_CYCLES", 0)), int(c.get("SQ_BUSY_CYCLES", 0)), int(gui),
-                                              round(clock, 3), f"{rate:.3e}", round(rate / 1.2288e12, 3)]) + "\n")
+                                              round(clock, 3), f"{rate:.3e}", round(rate / 1.2288e12, 3),
+                                              round(c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                                              round(c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                                              round(c.get("SQ_ACTIVE_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                                              round(c.get("SQ_INSTS_VALU", 0) * 3.534 / (ms * 1e-3 * 1024 * 2.4e9), 3) if ms > 0 else 0]) + "\n")
+            short = k.replace("rsv::", "").split("<")[0]
+            latest["kernels"][short] = {"avg_ms": ms, "hbm_bytes_corrected": int((2 * fetch + write) * 1024),
+                                        "SQ_INSTS_VALU": int(c.get("SQ_INSTS_VALU", 0)), "eff_clock_GHz": round(clock, 3)}
+    with open(os.path.join(dst, "pmc_latest.json"), "w") as f:
+        json.dump(latest, f, indent=1)
     print("wrote profiles/" + tag + "_*")
 
 
