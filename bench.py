@@ -311,10 +311,11 @@ def main():
         gen.manual_seed(1)
         d_in = torch.randint(0, 0x7FFFFFFF, (m, 16), dtype=torch.int32, device=dev, generator=gen)
         d_out = torch.empty_like(d_in)
-        ctx.poseidon2_permute(d_in, d_out)
+        for _ in range(3):  # untimed: module load, clocks back up after the host-side pause above
+            ctx.poseidon2_permute(d_in, d_out)
         ctx.synchronize()
         t1 = time.perf_counter()
-        reps = 5
+        reps = 20
         for _ in range(reps):
             ctx.poseidon2_permute(d_in, d_out)
         ctx.synchronize()

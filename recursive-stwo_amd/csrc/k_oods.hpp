@@ -87,7 +87,7 @@ __device__ __noinline__ void q_internal(QM31* s) {
 // The 86-constraint accumulator and the value it must equal (composition/src/lib.rs:60-120) for one proof whose
 // sampled values sit at their fixed word offsets behind `w`.  Shared by k_oods and by the probe k_oods_probe
 // (rsv_oods_eval), so that the evaluation can be checked on its own, on arbitrary samples.
-__device__ __noinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum, QM31 z,
+__device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum, QM31 z,
                                  QM31 alpha, QM31 rc, QM31 ox, QM31& acc_out, QM31& expected_out) {
     EvalCtx e;
     e.rc = rc; e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
@@ -325,7 +325,10 @@ __device__ __noinline__ void oods_eval_row(const uint32_t* w, uint32_t lp, uint3
     }
 }
 
-__global__ __launch_bounds__(64) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+// 4 waves per SIMD asked for (<= 128 registers, the rest spilled to scratch): the kernel is one latency-bound wave per
+// SIMD that lives for milliseconds underneath the Merkle kernels, and every 128 registers it holds cost that SIMD a
+// Merkle wave for as long.
+__global__ __launch_bounds__(64, 4) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                              uint32_t n, const ProofMeta* __restrict__ metas,
                                              ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
                                              uint32_t n_pi) {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void k_oods_row_probe(const uint32_t* __restri
 // Probe (rsv_oods_eval): item i = a proof prefix of OODS_PREFIX_WORDS words (only the sampled values are read) plus
 // 26 parameter words lp, lq, plonk_sum, poseidon_sum, z, alpha, random_coeff, oods.x; out = accumulator | expected.
 constexpr uint32_t OODS_PARAM_WORDS = 26;
-__global__ __launch_bounds__(64) void k_oods_probe(const uint32_t* __restrict__ prefix, uint32_t prefix_words,
+__global__ __launch_bounds__(64, 4) void k_oods_probe(const uint32_t* __restrict__ prefix, uint32_t prefix_words,
                                                    const uint32_t* __restrict__ params, uint32_t* __restrict__ out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
