@@ -22,11 +22,12 @@ struct RowHashArgs {
     const uint32_t* ids;   // slot -> proof (nullptr: identity)
 };
 
-__global__ __launch_bounds__(256) void k_row_hash(RowHashArgs a) {
+__global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     RSV_TAG(2);
+    RSV_FUSED_SELECT(f, a, bx);
     const uint32_t G = a.G, per_block = 256 / G;
     const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
-    const uint32_t slot = blockIdx.x * per_block + grp;
+    const uint32_t slot = bx * per_block + grp;
     const int t = blockIdx.y;
     if (grp >= per_block || slot >= a.n) return;
     const uint32_t p = a.ids ? a.ids[slot] : slot;
@@ -163,15 +164,16 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_trace_merkle(Fused<MerkleArgs> f) {
     RSV_TAG(3);
+    RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed;
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t slot_ = blockIdx.x * per_block + grp;
+    const uint32_t slot_ = bx * per_block + grp;
     const int t = blockIdx.y;
     bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
@@ -293,8 +295,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(MerkleArgs a) {
 // blockIdx.y = 0 is the FRI first-layer tree (one QM31 column at each distinct
 // column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_pair_merkle(Fused<MerkleArgs> f) {
     RSV_TAG(4);
+    RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
     __shared__ uint32_t xcol[BLOCK][8];     // phase B (nodes with their column folded in), data levels only
     __shared__ uint32_t xch2[BLOCK][8];     // path emission only: pre-column node hashes at data levels
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_merkle(MerkleArgs a) {
     __shared__ uint32_t xneed[2];
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t slot_ = blockIdx.x * per_block + grp;
+    const uint32_t slot_ = bx * per_block + grp;
     const uint32_t slot = blockIdx.y;
     bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;

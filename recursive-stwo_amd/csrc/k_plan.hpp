@@ -22,6 +22,24 @@ struct PlanPtrs {
     __device__ uint32_t proof_of(uint32_t slot) const { return ids ? ids[slot] : p0 + slot; }
 };
 
+// One launch over several n_queries buckets of a mixed batch: every per-query kernel takes up to MAX_FUSED argument
+// sets (one per bucket: its own lanes-per-proof G, tables and workspace) and a workgroup finds its set from its block
+// index.  A batch of many small buckets is then one launch per stage instead of one per bucket and stage, and the
+// buckets' tails fill with each other's workgroups.
+constexpr int MAX_FUSED = 8;
+template <class Args>
+struct Fused {
+    uint32_t nb;
+    uint32_t first_block[MAX_FUSED + 1];  // first blockIdx.x of set i; [nb] = grid size
+    Args a[MAX_FUSED];
+};
+// workgroup-uniform: the argument set of this block and its block index inside that set
+#define RSV_FUSED_SELECT(FUSED_, ARGS_, BX_)                                                            \
+    uint32_t fused_i_ = 0;                                                                               \
+    while (fused_i_ + 1 < (FUSED_).nb && blockIdx.x >= (FUSED_).first_block[fused_i_ + 1]) fused_i_++;    \
+    const auto& ARGS_ = (FUSED_).a[fused_i_];                                                            \
+    const uint32_t BX_ = blockIdx.x - (FUSED_).first_block[fused_i_]
+
 __device__ inline int sample_index(int t, int col, int s) {
     if (t == 0) return S_T0 + col;
     if (t == 1) return S_T1 + col;
@@ -190,10 +208,17 @@ __device__ __forceinline__ uint32_t m128_first_gt(M128 a, uint32_t x, uint32_t n
     return none;
 }
 
+struct PlanArgs {
+    uint32_t n;
+    PlanPtrs pl;
+};
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                                                    uint32_t n, const ProofMeta* __restrict__ metas,
-                                                    ProofCtx* __restrict__ ctxs, PlanPtrs pl) {
+                                                    const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs,
+                                                    Fused<PlanArgs> f) {
+    RSV_FUSED_SELECT(f, pa, bx);
+    const uint32_t n = pa.n;
+    const PlanPtrs& pl = pa.pl;
     __shared__ unsigned long long F[64][32][2];   // per_block <= 64 proofs, levels 0..30
     __shared__ uint32_t raw[BLOCK], sq[BLOCK];
     __shared__ uint8_t sp[BLOCK];
@@ -202,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ 
     __shared__ uint32_t wsum[64][32];             // wf[l + 1]
     const uint32_t G = pl.G, per_block = BLOCK / G;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t slot = blockIdx.x * per_block + grp;
+    const uint32_t slot = bx * per_block + grp;
     bool livep = grp < per_block && slot < n;
     const uint32_t p = livep ? pl.proof_of(slot) : 0u;
     const ProofMeta* m = livep ? &metas[p] : nullptr;

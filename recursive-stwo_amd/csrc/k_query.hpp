@@ -79,11 +79,12 @@ __device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n
 __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q_eq(eval, folded); }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_query(QueryArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     __shared__ uint32_t xq[BLOCK][4];
+    RSV_FUSED_SELECT(f, a, bx);
     const uint32_t G = a.pl.G, per_block = BLOCK / G;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
-    const uint32_t slot = blockIdx.x * per_block + grp;
+    const uint32_t slot = bx * per_block + grp;
     bool live = grp < per_block && slot < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
