@@ -876,3 +876,45 @@ def test_last_layer_check_probe(rsv):
         assert rsv.last_layer_check(c2, xs, good).sum() == 0  # the top coefficient weighs on every point (weights are products of x's: nonzero w.h.p.)
     with pytest.raises(ValueError):
         rsv.line_eval(np.zeros((3, 4), np.uint32), [1])  # not a power of two
+
+
+def test_many_distinct_query_counts_in_one_batch(rsv):
+    """More n_queries buckets than one fused launch holds (MAX_FUSED = 8): the header word n_queries of genuine proofs
+    is rewritten to twelve other values and each proof is verified under the matching configuration (16 configurations
+    = RSV_MAX_CFGS in one call, 16 distinct n_queries), so every one parses, passes the
+    proof of work (n_queries is not part of the transcript before it) and fails in the Merkle stages with its own
+    lane geometry; genuine proofs of four shapes sit in between.  Verdict and reason == the oracle's, and a second
+    pass through the same context (workspaces already grown) gives the same."""
+    import torch
+    base = {n: read_proof(n) for n in ("recursive_proof_16_15.bin", "level13-1.bin", "level2-1.bin", "level1-5.bin")}
+    batch, cfgs = [], []
+    for k in (1, 2, 3, 5, 7, 9, 12, 13, 20, 33, 64, 128):
+        name = ("recursive_proof_16_15.bin", "level13-1.bin")[k % 2]
+        c0 = fixture_cfg(name)
+        b = bytearray(base[name])
+        b[4 * 13:4 * 13 + 4] = int(k).to_bytes(4, "little")
+        batch.append(bytes(b))
+        cfgs.append(type(c0)(c0.pow_bits, c0.log_blowup_factor, c0.log_last_layer_degree_bound, k))
+        g = list(base)[len(batch) % 4]
+        batch.append(base[g]); cfgs.append(fixture_cfg(g))
+    batch = batch * 3
+    cfgs = cfgs * 3
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
+    assert diff.size == 0, [(int(i), int(cfgs[i].n_queries), int(reason[i]), int(oreason[i])) for i in diff[:10]]
+    assert int(acc.sum()) == 3 * 12  # exactly the genuine proofs
+    blob, offsets = rsv.pack(batch)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    n = len(batch)
+    ctx = rsv.Context(0)
+    pc = ctx.prepare_cfg(cfgs, n)
+    for _ in range(2):
+        d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=pc)
+        ctx.synchronize()
+        assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
+    ctx.close()
