@@ -918,3 +918,36 @@ def test_many_distinct_query_counts_in_one_batch(rsv):
         ctx.synchronize()
         assert d_acc.cpu().numpy().tolist() == oacc.tolist() and d_reason.cpu().numpy().tolist() == oreason.tolist()
     ctx.close()
+
+
+def test_mixed_batch_split_into_several_launch_groups(rsv, monkeypatch):
+    """A mixed batch whose per-query workspaces exceed the budget: the launcher cuts it into several groups of
+    (bucket, slot range) entries, some buckets split across groups.  Verdicts == those of the unconstrained run ==
+    the oracle's on the distinct inputs."""
+    import torch
+    names = ["level1-5.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level8-1.bin", "level13-1.bin", "level10-1.bin"]
+    proofs = {x: read_proof(x) for x in names}
+    n = 2400
+    batch, cfgs, want_names = [], [], []
+    for i in range(n):
+        x = names[i % len(names)]
+        batch.append(ob.tamper(proofs[x], i) if i % 13 == 4 else proofs[x])
+        cfgs.append(fixture_cfg(x))
+    tam = [i for i in range(n) if i % 13 == 4]
+    oacc, oreason = ob.verify_batch([batch[i] for i in tam], [cfgs[i] for i in tam])
+    want_acc, want_reason = np.ones(n, np.uint8), np.zeros(n, np.uint8)
+    want_acc[tam], want_reason[tam] = oacc, oreason
+    blob, offsets = rsv.pack(batch)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    for budget in ("64", "8192"):
+        monkeypatch.setenv("RSV_WS_BUDGET_MB", budget)
+        ctx = rsv.Context(0)
+        d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=ctx.prepare_cfg(cfgs, n))
+        ctx.synchronize()
+        assert np.array_equal(d_acc.cpu().numpy(), want_acc), budget
+        assert np.array_equal(d_reason.cpu().numpy(), want_reason), budget
+        ctx.close()
