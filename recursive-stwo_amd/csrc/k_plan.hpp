@@ -459,4 +459,120 @@ __global__ __launch_bounds__(64) void k_qconst(const uint8_t* __restrict__ blob,
     }
 }
 
+// ------------------------------------------------------------------ k_qconst_row
+// The same constants with ONE PROOF PER 16-LANE ROW, for batches too small to fill the machine: k_qconst's 136-step
+// chain of alpha powers and its ~134 column terms are pure latency on the critical path of a small batch
+// (transcript -> k_qconst -> k_query -> FRI trees).  Lane i owns the powers after^(16t + i) (start after^i, step
+// after^16) and therefore the column terms whose running index is i mod 16; the order in which columns meet powers is
+// a compile-time table per kind of size group (QTAB), the lanes' partial sums are added with a row all-reduce.
+__host__ __device__ constexpr int sample_index_c(int t, int col, int s) {
+    return t == 0 ? S_T0 + col : t == 1 ? S_T1 + col : t == 3 ? S_T3 + col
+         : S_T2 + (col < 4 ? col : col < 8 ? 4 + 2 * (col - 4) + s : col < 12 ? 12 + (col - 8) : 16 + 2 * (col - 12) + s);
+}
+struct QTab {
+    uint16_t n[4];               // entries per kind: 0 = the M group (composition columns), 1 = plonk columns only,
+    uint8_t si[4][N_APOW];       //                   2 = poseidon columns only, 3 = both (equal log sizes)
+    uint8_t batch[4][N_APOW];
+};
+__host__ __device__ constexpr QTab make_qtab() {
+    QTab q{};
+    for (int kind = 0; kind < 4; kind++) {
+        int k = 0;
+        const int n_batches = kind == 0 ? 1 : 2;
+        for (int bi = 0; bi < n_batches; bi++)
+            for (int t = 0; t < 4; t++) {
+                int c0 = 0, c1 = 0;
+                if (kind == 0) { if (t != 3) continue; c0 = 0; c1 = 8; }
+                else {
+                    if (t == 3) continue;
+                    c0 = (kind == 1 || kind == 3) ? 0 : (int)plonk_cols(t);
+                    c1 = (kind == 2 || kind == 3) ? (int)tree_cols(t) : (int)plonk_cols(t);
+                }
+                for (int col = c0; col < c1; col++) {
+                    const int ns = (int)n_samples_of(t, col);
+                    if (bi == 1 && ns != 2) continue;
+                    q.si[kind][k] = (uint8_t)sample_index_c(t, col, bi == 1 ? 0 : ns - 1);
+                    q.batch[kind][k] = (uint8_t)bi;
+                    k++;
+                }
+            }
+        q.n[kind] = (uint16_t)k;
+    }
+    return q;
+}
+__constant__ QTab QTAB = make_qtab();
+static_assert(make_qtab().n[3] <= N_APOW && make_qtab().n[3] == 134 && make_qtab().n[0] == 8, "alpha powers kept for the quotient numerators");
+
+__global__ __launch_bounds__(256) void k_qconst_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                    uint32_t n, const ProofMeta* __restrict__ metas,
+                                                    ProofCtx* __restrict__ ctxs) {
+    const uint32_t i = threadIdx.x & 15u;
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (p >= n) return;  // whole rows leave together (DPP needs every lane of a live row)
+    const ProofMeta& m = metas[p];
+    if (m.reason != R_OK) return;
+    ProofCtx& c = ctxs[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const uint32_t M = m.M, A = m.A, B = m.B;
+    const uint32_t sizes[3] = {M, A == B ? A : umax(A, B), A == B ? 0u : umin(A, B)};
+    const uint32_t n_sizes = A == B ? 2u : 3u;
+    auto sel = [](bool cnd, QM31 a, QM31 b) {
+        return q_mk(cnd ? a.a.a : b.a.a, cnd ? a.a.b : b.a.b, cnd ? a.b.a : b.b.a, cnd ? a.b.b : b.b.b);
+    };
+    auto sum16 = [](QM31 x) { return q_mk(sum_row(x.a.a), sum_row(x.a.b), sum_row(x.b.a), sum_row(x.b.b)); };
+    // alpha_k = -2u * after^k (data_structures.rs:162-189); lane i: k = i, i + 16, ...
+    const QM31 after = ldq(c.after), one = q_one();
+    const QM31 a2 = q_mul(after, after), a4 = q_mul(a2, a2), a8 = q_mul(a4, a4), a16 = q_mul(a8, a8);
+    QM31 start = sel(i & 1u, after, one);
+    start = q_mul(start, sel(i & 2u, a2, one));
+    start = q_mul(start, sel(i & 4u, a4, one));
+    start = q_mul(start, sel(i & 8u, a8, one));
+    start = q_mul(start, q_mk(0, 0, m_neg(2), 0));
+    {
+        QM31 cur = start;
+#pragma unroll 1
+        for (uint32_t k = i; k < (uint32_t)N_APOW; k += 16u) { stq(c.apow[k], cur); cur = q_mul(cur, a16); }
+    }
+    const QM31 ox = ldq(c.oods_x), oy = ldq(c.oods_y);
+    for (uint32_t g = 0; g < n_sizes; g++) {
+        const uint32_t l = sizes[g];
+        const uint32_t kind = l == M ? 0u : (A == B ? 3u : (l == A ? 1u : 2u));
+        // batch 0: OODS point; batch 1: OODS - g_{component log size} (answer/src/lib.rs:62-72)
+        const uint32_t comp_log = (l == A) ? m.lp : m.lq;
+        CPoint step = cp_gen_mul(1u << (31u - comp_log));
+        step.y = m_neg(step.y);
+        const QM31 sx = q_sub(q_mul_m(ox, step.x), q_mul_m(oy, step.y));
+        const QM31 sy = q_add(q_mul_m(ox, step.y), q_mul_m(oy, step.x));
+        QM31 sa0 = q_zero(), sb0 = q_zero(), sa1 = q_zero(), sb1 = q_zero(), cur = start;
+        const uint32_t cnt = QTAB.n[kind];
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 16u) {  // uniform trip count; the last round is partly masked
+            const uint32_t k = k0 + i;
+            if (k < cnt) {
+                const bool b1 = QTAB.batch[kind][k] != 0;
+                const QM31 v = ldq(w + SAMPLES.off[QTAB.si[kind][k]]);
+                const QM31 py = b1 ? sy : oy;
+                // complex_conjugate_line_coeffs_var (data_structures.rs:132-160)
+                const QM31 ta = q_mul_c(cur, v.b);
+                const QM31 tb = q_mul_c(cur, c_sub(c_mul(v.a, py.b), c_mul(v.b, py.a)));
+                sa0 = sel(b1, sa0, q_add(sa0, ta)); sb0 = sel(b1, sb0, q_add(sb0, tb));
+                sa1 = sel(b1, q_add(sa1, ta), sa1); sb1 = sel(b1, q_add(sb1, tb), sb1);
+            }
+            cur = q_mul(cur, a16);
+        }
+        sa0 = sum16(sa0); sb0 = sum16(sb0); sa1 = sum16(sa1); sb1 = sum16(sb1);
+        if (i == 0) {
+            const uint32_t n_batches = (l == M) ? 1u : 2u;
+            for (uint32_t bi = 0; bi < n_batches; bi++) {
+                QBatch& qb = c.batch[g][bi];
+                const QM31 px = bi ? sx : ox, py = bi ? sy : oy;
+                stq(qb.sa, bi ? sa1 : sa0); stq(qb.sb, bi ? sb1 : sb0);
+                qb.prx[0] = px.a.a; qb.prx[1] = px.a.b; qb.pix[0] = px.b.a; qb.pix[1] = px.b.b;
+                qb.pry[0] = py.a.a; qb.pry[1] = py.a.b; qb.piy[0] = py.b.a; qb.piy[1] = py.b.b;
+            }
+            c.n_batches[g] = n_batches;
+        }
+    }
+}
+
 }  // namespace rsv

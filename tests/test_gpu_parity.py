@@ -951,3 +951,40 @@ def test_mixed_batch_split_into_several_launch_groups(rsv, monkeypatch):
         assert np.array_equal(d_acc.cpu().numpy(), want_acc), budget
         assert np.array_equal(d_reason.cpu().numpy(), want_reason), budget
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["row", "lane"])
+def test_qconst_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+    """Both forms of the query-independent quotient constants (one proof per 16-lane row / per lane): every fixture of
+    the standard inputs accepts, tampers keep the oracle's reasons, and the per-query quotient / fold values — which
+    consume every alpha power and every summed line coefficient — equal the oracle's for three size-group layouts
+    (A > B, A == B, A < B)."""
+    import torch
+    monkeypatch.setenv("RSV_QCONST", mode)
+    std = [e for e in manifest if len(e["inputs"]) == 3 and e["expect"] == "ok"]
+    batch = [read_proof(e["file"]) for e in std]
+    cfgs = [fixture_cfg(e["file"]) for e in std]
+    batch += [ob.tamper(batch[k], 7 + k) for k in range(len(std))]
+    cfgs += cfgs
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    assert acc[:len(std)].tolist() == [1] * len(std)
+    dev = torch.device("cuda:0")
+    for name in ("recursive_proof_16_15.bin", "level7-1.bin", "small_proof.bin"):
+        entry = next(e for e in manifest if e["file"] == name)
+        proof = read_proof(name)
+        nq, n_inner = entry["n_queries"], ob.proof_layout(proof)["n_inner"]
+        M = max(entry["log_size_plonk"] + 1, entry["log_size_poseidon"] + 2) + entry["log_blowup_factor"]
+        blob, offsets = rsv.pack([proof])
+        d_blob = torch.from_numpy(blob.copy()).to(dev)
+        d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        d_acc = torch.zeros(1, dtype=torch.uint8, device=dev)
+        d_qv = torch.zeros((1, nq, 4 * (8 + n_inner)), dtype=torch.int32, device=dev)
+        ctx = rsv.Context(0)
+        ctx.verify_hints(d_blob, d_off, 1, d_acc, None, cfg=fixture_cfg(name), inputs=entry_inputs(entry), shape=(nq, M, n_inner),
+                         d_query_values=d_qv)
+        ctx.synchronize()
+        assert int(d_acc.item()) == 1
+        assert np.array_equal(d_qv.cpu().numpy().view(np.uint32)[0], ob.query_dump(proof, entry_inputs(entry))), name
+        ctx.close()
