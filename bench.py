@@ -355,7 +355,7 @@ def main():
 
     cpu = None
     sample = args.cpu_sample
-    if sample != 0:
+    if sample != 0 and world == 1:  # the CPU baseline is a single-GPU-run figure (rank 0 at N = 1 only)
         threads = max(1, min(os.cpu_count() or 1, 16))
         if sample < 0:
             sample = 640 * threads  # ~5 s per thread at ~8 ms per proof
