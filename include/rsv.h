@@ -138,6 +138,32 @@ int rsv_poseidon2_half_permute(const uint32_t* left8, const uint32_t* right8,
                                const uint8_t* swap, uint32_t* out_rate8,
                                uint32_t* out_cap8, size_t n, int device);
 
+/* ---- f4: gate values of the emulated Poseidon2 ------------------------------
+ * Replaces the value side of poseidon_permute_emulated(left, right, is_swap)
+ * (primitives/poseidon31/src/emulated.rs:80-221): the permutation written as M4 / pow5m4 / pow5 / Hadamard /
+ * grand-sum / add / mul gates of the Plonk-without-Poseidon constraint system
+ * (constraint_system/src/plonk_without_poseidon.rs:113-305).  For each of n permutations, rows receives the QM31
+ * value of every variable the gadget appends to the circuit's witness, in allocation order, for a circuit whose
+ * constants are already cached (primitives/fields/src/qm31.rs:39-73: every call but a circuit's first):
+ *   rows[p][0 .. 12)    the swap gates, present when is_swap = Some(..) and zero when it is None
+ *   rows[p][12 .. 413)  the 401 variables of the permutation itself; rows[p][409 .. 413) are the output state
+ *                       (left half in the first two)
+ *   rows[p][413 .. 416) zero: padding to RSV_EMU_STRIDE rows, so that each permutation's rows are 52 whole 128-byte
+ *                       lines (the kernel is bound by HBM writes and stores whole aligned lines)
+ * left8 / right8: n x 8 canonical words (a half = two QM31 of four words each).  swap: NULL (all None) or n bytes,
+ * 0 = None, 1 = Some((false, _)), 2 = Some((true, _)); other values or words >= P give RSV_E_RANGE. */
+#define RSV_EMU_SWAP_ROWS 12
+#define RSV_EMU_ROWS 413
+#define RSV_EMU_STRIDE 416
+int rsv_poseidon2_emulated(const uint32_t* left8, const uint32_t* right8, const uint8_t* swap,
+                           uint32_t* rows /* [n][RSV_EMU_STRIDE][4] */, size_t n, int device);
+/* Device-resident form on the context's stream.  d_left8 / d_right8 / d_rows must be 16-byte aligned (d_rows on a
+ * 128-byte line for full speed).  d_bad
+ * (device u32, may be NULL) is set to 1 on a range error and left untouched otherwise, as for
+ * rsv_poseidon2_permute_dev. */
+int rsv_poseidon2_emulated_dev(rsv_ctx* ctx, const uint32_t* d_left8, const uint32_t* d_right8, const uint8_t* d_swap,
+                               uint32_t* d_rows, size_t n, uint32_t* d_bad);
+
 /* ---- a5: Poseidon31 Merkle hasher -----------------------------------------
  * Replaces Poseidon31MerkleHasherVar::{hash_tree, hash_tree_with_column,
  * hash_m31_columns_get_rate, ...} (primitives/merkle/src/lib.rs:9-181) ==

@@ -123,6 +123,11 @@ static const m31 RC_LAST[4][16] = {
     {0x7c93e00e, 0x561fbb4d, 0x1178907b, 0x02737406, 0x32fb24f1, 0x6323b60a, 0x6ab12418, 0x42c99cea,
      0x155a0b97, 0x53d1c6aa, 0x2bd20347, 0x279b3d73, 0x4f5f3c70, 0x0245af6c, 0x238359d3, 0x49966a59}};
 
+/* the tables above, for rsv_emulated.c (0: first four rounds [4][16], 1: partial [14], 2: last four [4][16]) */
+const uint32_t* rsvo_round_constants(int which) {
+    return which == 0 ? &RC_FIRST[0][0] : which == 1 ? RC_PARTIAL : which == 2 ? &RC_LAST[0][0] : NULL;
+}
+
 static __thread uint64_t g_perm_count;
 uint64_t rsvo_perm_count(void) { return g_perm_count; }
 void rsvo_perm_count_reset(void) { g_perm_count = 0; }

@@ -74,6 +74,25 @@ int rsvo_fri_folded(const uint8_t* proof, size_t len, const rsv_public_input* pi
 int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
                    size_t cap, uint32_t* cols, uint32_t* n_trees, uint32_t* n_queries);
 
+/* ---- rsv_emulated.c: the emulated Poseidon2 gadget over a minimal Plonk-without-Poseidon constraint system
+ * (primitives/poseidon31/src/emulated.rs:80-221, constraint_system/src/plonk_without_poseidon.rs) */
+typedef struct rsvo_ecs rsvo_ecs;
+enum { RSVO_VAR_FIXED = 0, RSVO_VAR_WITNESS = 1, RSVO_VAR_CONSTANT = 2, RSVO_VAR_GATE = 3 };
+const uint32_t* rsvo_round_constants(int which);
+rsvo_ecs* rsvo_ecs_new(void);
+void rsvo_ecs_free(rsvo_ecs* cs);
+size_t rsvo_ecs_n_vars(const rsvo_ecs* cs);
+size_t rsvo_ecs_n_rows(const rsvo_ecs* cs);
+uint32_t rsvo_ecs_new_witness_m31(rsvo_ecs* cs, uint32_t v);
+uint32_t rsvo_ecs_new_witness_qm31(rsvo_ecs* cs, const uint32_t* v4);
+uint32_t rsvo_ecs_qm31_from_m31(rsvo_ecs* cs, const uint32_t* m31_vars4);
+int rsvo_ecs_permute_emulated(rsvo_ecs* cs, const uint32_t* left2, const uint32_t* right2, int swap_mode,
+                              uint32_t bit_var, uint32_t* out4);
+size_t rsvo_ecs_check_arithmetics(const rsvo_ecs* cs);
+/* vars4: [n_vars][4]; kind: [n_vars] RSVO_VAR_*; rows7: [n_rows][7] = a, b, c wires, op1..op4 */
+void rsvo_ecs_export(const rsvo_ecs* cs, uint32_t* vars4, uint8_t* kind, uint32_t* rows7);
+int rsvo_ecs_set_vars(rsvo_ecs* cs, size_t first, const uint32_t* vars4, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

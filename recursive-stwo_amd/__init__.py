@@ -10,6 +10,7 @@ every call raises.
 Reference items mirrored (values only; see include/rsv.h for file:line):
   poseidon2_permute        primitives/poseidon31/src/implementation.rs:108-149
   half_permute             Poseidon2HalfVar::permute, primitives/poseidon31/src/lib.rs:282-423
+  poseidon2_emulated       poseidon_permute_emulated (gate values), primitives/poseidon31/src/emulated.rs:80-221
   hash_node                Poseidon31MerkleHasherVar, primitives/merkle/src/lib.rs:9-181
   merkle_path_root         SinglePathMerkleProofVar::verify, components/recursive/data_structures/src/lib.rs:315-354
   transcript               FiatShamirResults::compute, components/recursive/fiat_shamir/src/lib.rs:31-176
@@ -149,6 +150,8 @@ def _load() -> ctypes.CDLL:
         "rsv_ctx_wait_stream": (ctypes.c_int, [vp, vp]),
         "rsv_stream_wait_ctx": (ctypes.c_int, [vp, vp]),
         "rsv_poseidon2_half_permute": (ctypes.c_int, [_u32p, _u32p, _u8p, _u32p, _u32p, sz, ctypes.c_int]),
+        "rsv_poseidon2_emulated": (ctypes.c_int, [_u32p, _u32p, _u8p, _u32p, sz, ctypes.c_int]),
+        "rsv_poseidon2_emulated_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, sz, vp]),
         "rsv_merkle_hash_node": (ctypes.c_int, [_u32p, _u32p, _u32p, sz, _u32p, sz, ctypes.c_int]),
         "rsv_merkle_path_root": (ctypes.c_int, [_u32p, _u32p, _u32p, _u32p, ctypes.c_uint32, _u32p, sz, ctypes.c_int]),
         "rsv_transcript": (ctypes.c_int, [_u8p, sz, _u32p, sz, ctypes.c_int]),
@@ -189,6 +192,7 @@ def _load() -> ctypes.CDLL:
 lib = _load()
 EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_destroy", "rsv_ctx_synchronize",
            "rsv_ctx_stream", "rsv_ctx_wait_stream", "rsv_stream_wait_ctx", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
+           "rsv_poseidon2_emulated", "rsv_poseidon2_emulated_dev",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
@@ -306,6 +310,24 @@ def half_permute(left, right, swap=None, device: int = 0):
                                           rate.ctypes.data_as(_u32p), cap.ctypes.data_as(_u32p), n, device),
            "rsv_poseidon2_half_permute")
     return rate, cap
+
+
+EMU_SWAP_ROWS, EMU_ROWS, EMU_STRIDE = 12, 413, 416  # RSV_EMU_SWAP_ROWS, RSV_EMU_ROWS, RSV_EMU_STRIDE
+
+
+def poseidon2_emulated(left, right, swap=None, device: int = 0) -> np.ndarray:
+    """Gate values of poseidon_permute_emulated for n permutations: (n, 416, 4) QM31 rows (rows 0..11 = the swap
+    gates, zero for is_swap None; rows 409..412 = the output state; rows 413..415 zero padding).  swap: None or n bytes, 0 = None,
+    1 = Some((false, _)), 2 = Some((true, _))."""
+    l = _u32(left).reshape(-1, 8)
+    r = _u32(right).reshape(-1, 8)
+    n = l.shape[0]
+    sw = None if swap is None else np.ascontiguousarray(swap, dtype=np.uint8)
+    rows = np.empty((n, EMU_STRIDE, 4), np.uint32)
+    _check(lib.rsv_poseidon2_emulated(l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p),
+                                      None if sw is None else sw.ctypes.data_as(_u8p), rows.ctypes.data_as(_u32p), n,
+                                      device), "rsv_poseidon2_emulated")
+    return rows
 
 
 def hash_node(children, cols, device: int = 0) -> np.ndarray:
@@ -487,6 +509,14 @@ class Context:
         self.acquire_from_torch()
         _check(lib.rsv_poseidon2_permute_dev(self._h, d_in.data_ptr(), d_out.data_ptr(), n,
                                              d_bad.data_ptr() if d_bad is not None else None), "rsv_poseidon2_permute_dev")
+
+    def poseidon2_emulated(self, d_left, d_right, d_swap, d_rows, d_bad=None):
+        """d_left / d_right: (n, 8) u32; d_swap: None or (n,) u8; d_rows: (n, 416, 4) u32 (rsv_poseidon2_emulated_dev)."""
+        n = d_left.numel() // 8
+        self.acquire_from_torch()
+        _check(lib.rsv_poseidon2_emulated_dev(self._h, d_left.data_ptr(), d_right.data_ptr(),
+                                              d_swap.data_ptr() if d_swap is not None else None, d_rows.data_ptr(), n,
+                                              d_bad.data_ptr() if d_bad is not None else None), "rsv_poseidon2_emulated_dev")
 
     def verify_batch(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS):
         pi = make_inputs(inputs)

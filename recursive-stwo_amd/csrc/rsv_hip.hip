@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "primitives.hpp"
+#include "k_emulated.hpp"
 #include "verify.hpp"
 
 using namespace rsv;
@@ -243,6 +244,54 @@ int rsv_poseidon2_half_permute(const uint32_t* left8, const uint32_t* right8, co
     if (bad) return RSV_E_RANGE;
     if (out_rate8) HIP_TRY(hipMemcpy(out_rate8, drate.p, 32 * n, hipMemcpyDeviceToHost));
     if (out_cap8) HIP_TRY(hipMemcpy(out_cap8, dcap.p, 32 * n, hipMemcpyDeviceToHost));
+    return RSV_OK;
+}
+
+// ---------------------------------------------------------------- f4
+static_assert(RSV_EMU_STRIDE == EMU_STRIDE && RSV_EMU_ROWS == EMU_ROWS && RSV_EMU_SWAP_ROWS == EMU_SWAP_ROWS,
+              "rsv.h and k_emulated.hpp disagree");
+
+int rsv_poseidon2_emulated_dev(rsv_ctx* c, const uint32_t* d_left, const uint32_t* d_right, const uint8_t* d_swap,
+                               uint32_t* d_rows, size_t n, uint32_t* d_bad) {
+    if (!c || (n && (!d_left || !d_right || !d_rows))) return RSV_E_NULL;
+    if (n == 0) return RSV_OK;
+    if (n > ((size_t)1 << 26)) return RSV_E_SIZE;
+    if (((uintptr_t)d_left & 15) || ((uintptr_t)d_right & 15) || ((uintptr_t)d_rows & 15)) return RSV_E_SIZE;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_emulated, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_left, d_right, d_swap,
+                       reinterpret_cast<uint4*>(d_rows), n, d_bad);
+    HIP_TRY(hipGetLastError());
+    return RSV_OK;
+}
+
+int rsv_poseidon2_emulated(const uint32_t* left8, const uint32_t* right8, const uint8_t* swap, uint32_t* rows, size_t n,
+                           int device) {
+    if (n && (!left8 || !right8 || !rows)) return RSV_E_NULL;
+    if (n > ((size_t)1 << 22)) return RSV_E_SIZE;  // 2^22 permutations = 27.9 GB of rows
+    int rc = select_device(device);
+    if (rc != RSV_OK) return rc;
+    if (n == 0) return RSV_OK;
+    const size_t row_bytes = (size_t)EMU_STRIDE * 16 * n;
+    DevBuf dl, dr, ds, drows, dbad;
+    HIP_TRY(dl.alloc(32 * n));
+    HIP_TRY(dr.alloc(32 * n));
+    HIP_TRY(drows.alloc(row_bytes));
+    HIP_TRY(dbad.alloc(4));
+    HIP_TRY(hipMemset(dbad.p, 0, 4));
+    HIP_TRY(hipMemcpy(dl.p, left8, 32 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, right8, 32 * n, hipMemcpyHostToDevice));
+    if (swap) {
+        HIP_TRY(ds.alloc(n));
+        HIP_TRY(hipMemcpy(ds.p, swap, n, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_emulated, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, dl.as<const uint32_t>(),
+                       dr.as<const uint32_t>(), swap ? ds.as<const uint8_t>() : nullptr, drows.as<uint4>(), n,
+                       dbad.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, dbad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return RSV_E_RANGE;
+    HIP_TRY(hipMemcpy(rows, drows.p, row_bytes, hipMemcpyDeviceToHost));
     return RSV_OK;
 }
 

@@ -27,8 +27,8 @@ class PublicInput(ctypes.Structure):
 
 
 def build():
-    src = os.path.join(ROOT, "oracle", "rsv_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("rsv_oracle.c", "rsv_emulated.c", "rsv_oracle.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
 
 
@@ -506,3 +506,110 @@ def structural_mutants(proof: bytes):
     d = copy.deepcopy(base); d["last"] = d["last"] + d["last"]; emit("last doubled", d)
     d = copy.deepcopy(base); d["last"] = []; emit("last empty", d)
     return out
+
+
+# ---------------------------------------------------------------------------- emulated Poseidon2 (oracle/rsv_emulated.c)
+VAR_FIXED, VAR_WITNESS, VAR_CONSTANT, VAR_GATE = 0, 1, 2, 3
+lib.rsvo_ecs_new.restype = ctypes.c_void_p
+lib.rsvo_ecs_free.argtypes = [ctypes.c_void_p]
+lib.rsvo_ecs_n_vars.argtypes = [ctypes.c_void_p]
+lib.rsvo_ecs_n_vars.restype = sz
+lib.rsvo_ecs_n_rows.argtypes = [ctypes.c_void_p]
+lib.rsvo_ecs_n_rows.restype = sz
+lib.rsvo_ecs_new_witness_m31.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+lib.rsvo_ecs_new_witness_m31.restype = ctypes.c_uint32
+lib.rsvo_ecs_new_witness_qm31.argtypes = [ctypes.c_void_p, _u32p]
+lib.rsvo_ecs_new_witness_qm31.restype = ctypes.c_uint32
+lib.rsvo_ecs_qm31_from_m31.argtypes = [ctypes.c_void_p, _u32p]
+lib.rsvo_ecs_qm31_from_m31.restype = ctypes.c_uint32
+lib.rsvo_ecs_permute_emulated.argtypes = [ctypes.c_void_p, _u32p, _u32p, ctypes.c_int, ctypes.c_uint32, _u32p]
+lib.rsvo_ecs_check_arithmetics.argtypes = [ctypes.c_void_p]
+lib.rsvo_ecs_check_arithmetics.restype = sz
+lib.rsvo_ecs_export.argtypes = [ctypes.c_void_p, _u32p, _u8p, _u32p]
+lib.rsvo_ecs_set_vars.argtypes = [ctypes.c_void_p, sz, _u32p, sz]
+
+
+class EmulatedCS:
+    """The oracle's minimal Plonk-without-Poseidon constraint system with the emulated Poseidon2 gadget on it."""
+
+    def __init__(self):
+        self.h = ctypes.c_void_p(lib.rsvo_ecs_new())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.rsvo_ecs_free(self.h)
+            self.h = None
+
+    @property
+    def n_vars(self):
+        return lib.rsvo_ecs_n_vars(self.h)
+
+    @property
+    def n_rows(self):
+        return lib.rsvo_ecs_n_rows(self.h)
+
+    def witness_m31(self, v):
+        return lib.rsvo_ecs_new_witness_m31(self.h, int(v))
+
+    def witness_qm31(self, v4):
+        a = _u32(v4)
+        return lib.rsvo_ecs_new_witness_qm31(self.h, a.ctypes.data_as(_u32p))
+
+    def qm31_from_m31(self, vars4):
+        a = _u32(vars4)
+        return lib.rsvo_ecs_qm31_from_m31(self.h, a.ctypes.data_as(_u32p))
+
+    def permute(self, left2, right2, swap_bit_var=None):
+        """swap_bit_var None = is_swap None; else the variable index of the bit (is_swap = Some((value, var)))."""
+        l, r, out = _u32(left2), _u32(right2), np.zeros(4, np.uint32)
+        rc = lib.rsvo_ecs_permute_emulated(self.h, l.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p),
+                                           0 if swap_bit_var is None else 1, 0 if swap_bit_var is None else swap_bit_var,
+                                           out.ctypes.data_as(_u32p))
+        if rc != 0:
+            raise RuntimeError(f"rsvo_ecs_permute_emulated: {rc}")
+        return out
+
+    def check_arithmetics(self) -> int:
+        """0 = every row satisfies its gate equation, else 1 + the first failing row."""
+        return lib.rsvo_ecs_check_arithmetics(self.h)
+
+    def export(self):
+        nv, nr = self.n_vars, self.n_rows
+        v, k, r = np.zeros((nv, 4), np.uint32), np.zeros(nv, np.uint8), np.zeros((nr, 7), np.uint32)
+        lib.rsvo_ecs_export(self.h, v.ctypes.data_as(_u32p), k.ctypes.data_as(_u8p), r.ctypes.data_as(_u32p))
+        return v, k, r
+
+    def set_vars(self, first, vals):
+        a = _u32(vals).reshape(-1, 4)
+        rc = lib.rsvo_ecs_set_vars(self.h, first, a.ctypes.data_as(_u32p), len(a))
+        if rc != 0:
+            raise RuntimeError(f"rsvo_ecs_set_vars: {rc}")
+
+
+def emulated_rows(left8, right8, swap):
+    """Steady-state gate values of n emulated permutations, as the product lays them out ([n][416][4]; rows 0..11 are
+    the swap rows, zero when swap[p] == 0; rows 413..415 are zero padding).  swap[p]: 0 = None, 1 = Some((false, _)), 2 = Some((true, _)).  One warm-up
+    call caches the constants first, as every call but a circuit's first finds them."""
+    left8, right8 = _u32(left8).reshape(-1, 8), _u32(right8).reshape(-1, 8)
+    n = len(left8)
+    cs = EmulatedCS()
+    w = [cs.witness_qm31([0, 0, 0, 0]) for _ in range(4)]
+    cs.permute(w[:2], w[2:], None)
+    cs.permute(w[:2], w[2:], cs.witness_m31(0))
+    out = np.zeros((n, 416, 4), np.uint32)
+    spans = []
+    for p in range(n):
+        l = [cs.witness_qm31(left8[p, :4]), cs.witness_qm31(left8[p, 4:])]
+        r = [cs.witness_qm31(right8[p, :4]), cs.witness_qm31(right8[p, 4:])]
+        bit = None if swap[p] == 0 else cs.witness_m31(int(swap[p]) - 1)
+        first = cs.n_vars
+        cs.permute(l, r, bit)
+        spans.append((first, cs.n_vars, int(swap[p])))
+    v, k, _ = cs.export()
+    for p, (a, b, sw) in enumerate(spans):
+        assert not (k[a:b] == VAR_CONSTANT).any()
+        rows = v[a:b]
+        assert len(rows) == (413 if sw else 401)
+        out[p, (0 if sw else 12):413] = rows
+    assert cs.check_arithmetics() == 0
+    return out, cs, spans

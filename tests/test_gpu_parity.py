@@ -72,6 +72,88 @@ def test_half_permute_known_answer_with_swap(rsv):
         assert np.concatenate([rate[0], cap[0]]).tolist() == kat
 
 
+# ---------------------------------------------------------------------------------------------- f4: emulated Poseidon2
+def test_emulated_reference_test_on_gpu(rsv):
+    """primitives/poseidon31/src/emulated.rs:236-275 with the GPU's rows: the three permutes of the reference's test
+    give the known answer, and — written over the oracle constraint system's variables — every GPU value satisfies
+    the gate equations of check_arithmetics (constraint_system/src/plonk_without_poseidon.rs:410-598)."""
+    lo, hi = np.arange(8, dtype=np.uint32), np.arange(8, 16, dtype=np.uint32)
+    left, right, swap = np.stack([lo, lo, hi]), np.stack([hi, hi, lo]), np.array([0, 1, 2], np.uint8)
+    rows = rsv.poseidon2_emulated(left, right, swap)
+    assert rows.shape == (3, 416, 4)
+    for p in range(3):
+        assert rows[p, 409:413].reshape(-1).tolist() == KAT_OUT
+    want, cs, spans = ob.emulated_rows(left, right, swap)
+    assert np.array_equal(rows, want)
+    for p, (a, b, sw) in enumerate(spans):
+        cs.set_vars(a, rows[p, (0 if sw else 12):413])
+    assert cs.check_arithmetics() == 0
+    # and the equations do bite: one flipped GPU word fails a row
+    bad = rows[1, 40].copy()
+    bad[2] ^= 1
+    cs.set_vars(spans[1][0] + 40, bad)
+    assert cs.check_arithmetics() != 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 200])
+def test_emulated_rows_match_oracle(rsv, n):
+    rng = np.random.default_rng(100 + n)
+    left = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    right = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    swap = rng.integers(0, 3, n).astype(np.uint8)
+    left[0], right[0] = P - 1, 0
+    want, _, _ = ob.emulated_rows(left, right, swap)
+    assert np.array_equal(rsv.poseidon2_emulated(left, right, swap), want)
+    want0, _, _ = ob.emulated_rows(left, right, np.zeros(n, np.uint8))
+    assert np.array_equal(rsv.poseidon2_emulated(left, right, None), want0)
+    assert rsv.poseidon2_emulated(np.zeros((0, 8), np.uint32), np.zeros((0, 8), np.uint32)).shape == (0, 416, 4)
+
+
+def test_emulated_rejects_bad_inputs(rsv):
+    z = np.zeros((70, 8), np.uint32)
+    bad = z.copy()
+    bad[66, 3] = P
+    for l, r, sw in ((bad, z, None), (z, bad, None), (z, z, np.array([0] * 69 + [3], np.uint8))):
+        with pytest.raises(rsv.RsvError) as e:
+            rsv.poseidon2_emulated(l, r, sw)
+        assert e.value.code == -5
+
+
+def test_emulated_dev_large_batch_properties(rsv):
+    """2^16 permutations resident in HBM (436 MB of rows): the output rows are the plain permutation of the (possibly
+    exchanged) halves, the None-mode swap rows are zero, the structure of a partial round holds everywhere (row 9 of
+    round r is the sum of rows 7 and 8; rows 1-2 split limb 0), and a sample of permutations equals the oracle."""
+    import torch
+    n = 1 << 16
+    rng = np.random.default_rng(77)
+    left = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    right = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    swap = rng.integers(0, 3, n).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_l, d_r = torch.from_numpy(left.view(np.int32)).to(dev), torch.from_numpy(right.view(np.int32)).to(dev)
+    d_s = torch.from_numpy(swap).to(dev)
+    d_rows = torch.empty((n, 416, 4), dtype=torch.int32, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = rsv.Context(0)
+    ctx.poseidon2_emulated(d_l, d_r, d_s, d_rows, d_bad)
+    ctx.synchronize()
+    assert int(d_bad.item()) == 0
+    rows = d_rows.cpu().numpy().view(np.uint32)
+    state = np.where((swap == 2)[:, None], np.concatenate([right, left], 1), np.concatenate([left, right], 1))
+    assert np.array_equal(rows[:, 409:413].reshape(n, 16), rsv.poseidon2_permute(state))
+    assert not rows[swap == 0, :12].any() and not rows[:, 413:].any()
+    first_partial = 12 + 11 + 4 * 19
+    for r in (0, 13):
+        b = first_partial + 17 * r
+        s = (rows[:, b + 6].astype(np.uint64) + rows[:, b + 7]) % P
+        assert np.array_equal(s, rows[:, b + 8])
+        assert not rows[:, b, 1:].any() and not rows[:, b + 1, 0].any()
+    pick = rng.choice(n, 64, replace=False)
+    want, _, _ = ob.emulated_rows(left[pick], right[pick], swap[pick])
+    assert np.array_equal(rows[pick], want)
+    ctx.close()
+
+
 @pytest.mark.parametrize("n_cols", [0, 1, 4, 7, 8, 13, 16, 17, 21, 25, 48])
 def test_hash_node(rsv, n_cols):
     # column lengths 7/13/16/17/21/25 are the ones primitives/merkle/src/lib.rs:207-303 tests

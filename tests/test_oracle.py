@@ -505,3 +505,48 @@ def test_big_shape_reject_fixtures_behind_the_proof_of_work():
     t = ob.transcript_raw(dup)
     q = t[40 + 4 * int(t[1]):40 + 4 * int(t[1]) + 80] & ((1 << int(t[3])) - 1)
     assert len(set(q.tolist())) < 80 and t[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------- emulated Poseidon2
+EMULATED_KAT = [260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083, 755063943, 1682438524,
+                1265420601, 238640995, 200799880, 1659717477, 2080202267, 1269806256, 1287849264]
+
+
+def test_emulated_poseidon_reference_test():
+    """primitives/poseidon31/src/emulated.rs:236-275 replayed on the oracle's constraint system: 16 witness words
+    0..15 packed four to a QM31, permuted with is_swap None, Some((false, 0)) and — halves exchanged —
+    Some((true, 1)); every result is the known-answer state and every row passes check_arithmetics."""
+    cs = ob.EmulatedCS()
+    m = [cs.witness_m31(i) for i in range(16)]
+    left = [cs.qm31_from_m31(m[0:4]), cs.qm31_from_m31(m[4:8])]
+    right = [cs.qm31_from_m31(m[8:12]), cs.qm31_from_m31(m[12:16])]
+    outs = [cs.permute(left, right, None), cs.permute(left, right, 0), cs.permute(right, left, 1)]
+    v, kind, rows = cs.export()
+    for o in outs:
+        assert v[o].reshape(-1).tolist() == EMULATED_KAT
+    assert cs.check_arithmetics() == 0
+    assert len(rows) == cs.n_rows and len(v) == cs.n_vars
+    # every row is one of the six gate types of plonk_without_poseidon.rs:478-560
+    ops = {tuple(r[4:7]) for r in rows}
+    assert ops <= {(0, 0, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 0), (0, 1, 1)}
+    # a corrupted variable is caught by the gate equations
+    bad = v[outs[0][0]].copy()
+    bad[0] ^= 1
+    cs.set_vars(int(outs[0][0]), bad)
+    assert cs.check_arithmetics() != 0
+
+
+def test_emulated_poseidon_matches_plain_permutation():
+    """The gadget's outputs are poseidon2_permute of the (possibly exchanged) halves; constants are allocated once;
+    a steady-state call appends 401 variables (413 with a swap bit), as include/rsv.h states."""
+    rng = np.random.default_rng(11)
+    n = 24
+    left = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    right = rng.integers(0, P, (n, 8), dtype=np.uint32)
+    swap = rng.integers(0, 3, n).astype(np.uint8)
+    left[0], right[0] = 0, P - 1  # extremes
+    rows, cs, spans = ob.emulated_rows(left, right, swap)
+    state = np.where((swap == 2)[:, None], np.concatenate([right, left], 1), np.concatenate([left, right], 1))
+    want = ob.poseidon2_permute(state)
+    assert (rows[:, 409:413, :].reshape(n, 16) == want).all() and not rows[:, 413:].any()
+    assert (rows[swap == 0, :12] == 0).all()
