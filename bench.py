@@ -353,6 +353,31 @@ def main():
                                  "(tools/perm_ceiling.py, DESIGN §4)"}
         del d_in, d_out
 
+    # SURVEY §8f.4 widening: gate values of the emulated Poseidon2, HBM-write bound (65 B in, 6 656 B out per permutation)
+    emulated = None
+    if args.perm_log2 > 0 and world == 1:
+        m = 1 << min(args.perm_log2, 20)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(2)
+        d_l = torch.randint(0, 0x7FFFFFFF, (m, 8), dtype=torch.int32, device=dev, generator=gen)
+        d_r = torch.randint(0, 0x7FFFFFFF, (m, 8), dtype=torch.int32, device=dev, generator=gen)
+        d_s = torch.randint(0, 3, (m,), dtype=torch.uint8, device=dev, generator=gen)
+        d_rows = torch.empty((m, rsv.EMU_STRIDE, 4), dtype=torch.int32, device=dev)
+        for _ in range(2):
+            ctx.poseidon2_emulated(d_l, d_r, d_s, d_rows)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            ctx.poseidon2_emulated(d_l, d_r, d_s, d_rows)
+        ctx.synchronize()
+        edt = (time.perf_counter() - t1) / reps
+        ebytes = 65 + rsv.EMU_STRIDE * 16
+        emulated = {"perms_per_s": m / edt, "perms": m, "algorithmic_bytes_per_perm": ebytes, "bound": "hbm",
+                    "achieved_GBps": m * ebytes / edt / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+                    "frac": m * ebytes / edt / 1e9 / HBM_PEAK_GBPS}
+        del d_l, d_r, d_s, d_rows
+
     cpu = None
     sample = args.cpu_sample
     if sample != 0 and world == 1:  # the CPU baseline is a single-GPU-run figure (rank 0 at N = 1 only)
@@ -387,7 +412,7 @@ def main():
                    "batches_in_flight": args.inflight,
                    "exchange": "all_gather(accept bitmap) + all_reduce(count) per step, " + ("gloo (rehearsal)" if rehearsal else
                                ("nccl/RCCL" if world > 1 else "none (1 rank)"))},
-        "roofline": roofline, "cpu_baseline": cpu, "valu": valu,
+        "roofline": roofline, "cpu_baseline": cpu, "valu": valu, "emulated_poseidon2": emulated,
     }
     print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -22,9 +22,9 @@
 // permutation (three zero rows at the end) so that every permutation starts on a 128-byte line, and each wave stages
 // its rows in an LDS ring ([64 lanes][16 rows + 1] x 16 B) that is drained EIGHT rows = one full aligned line per
 // permutation at a time: a store instruction writes 8 complete lines (lanes 8k..8k+7 = the line of permutation k).
-// Measured alternatives: every lane storing its own rows (64 x 16 B at a 6.6 KB stride per instruction) and
-// per-round flushes of 7-12 rows at 16-byte alignment (2.4 TB/s: the lines at the ends of every segment are
-// written in two pieces a round apart, by which time the L2 has evicted the first).
+// Measured alternative: per-round flushes of 7-12 rows at 16-byte alignment reached 2.4 TB/s against 5.6 TB/s for
+// this form (the lines at the two ends of every segment were written in two pieces a round apart, by which time
+// the L2 had evicted the first).
 #pragma once
 #include "poseidon2.hpp"
 

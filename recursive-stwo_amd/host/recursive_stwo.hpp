@@ -7,6 +7,8 @@
 //   poseidon31::poseidon2_permute          primitives/poseidon31/src/implementation.rs:108-149
 //   Poseidon2HalfVar::{permute, permute_get_rate, permute_get_capacity, swap_permute_get_*}
 //                                          primitives/poseidon31/src/lib.rs:251-423
+//   poseidon31::emulated::poseidon_permute_emulated{,_batch}   (witness values of the gate-level permutation)
+//                                          primitives/poseidon31/src/emulated.rs:80-221
 //   Poseidon31MerkleHasherVar::*           primitives/merkle/src/lib.rs:9-181
 //   ChannelVar::{mix_root, draw_felts, mix_one_felt, mix_two_felts}
 //                                          primitives/channel/src/lib.rs:24-58
@@ -109,6 +111,45 @@ struct Poseidon2HalfVar {
     }
 };
 using HashVar = Poseidon2HalfVar;
+
+namespace poseidon31::emulated {
+// What one call of poseidon_permute_emulated appends to a Plonk-without-Poseidon circuit's `variables` once its
+// constants are cached (primitives/poseidon31/src/emulated.rs:80-221): `swap_rows` (12, only for is_swap = Some),
+// then `rows` (401); `out_left` / `out_right` are the values of the returned Poseidon2HalfEmulatedVar pair.
+struct EmulatedWitness {
+    std::vector<QM31> swap_rows, rows;
+    std::array<QM31, 2> out_left{}, out_right{};
+};
+using IsSwap = std::optional<bool>;  // the bit's value; its variable index stays with the caller's circuit
+
+// Batch form: one GPU launch for all permutations (rsv_poseidon2_emulated).
+inline std::vector<EmulatedWitness> poseidon_permute_emulated_batch(const std::vector<std::array<QM31, 2>>& left,
+                                                                     const std::vector<std::array<QM31, 2>>& right,
+                                                                     const std::vector<IsSwap>& is_swap) {
+    const size_t n = left.size();
+    if (right.size() != n || is_swap.size() != n) throw DeviceError("poseidon_permute_emulated_batch: ragged input", RSV_E_SIZE);
+    std::vector<uint32_t> l(8 * n), r(8 * n), rows((size_t)RSV_EMU_STRIDE * 4 * n);
+    std::vector<uint8_t> sw(n);
+    for (size_t p = 0; p < n; p++) {
+        for (int i = 0; i < 8; i++) { l[8 * p + i] = left[p][i / 4][i % 4]; r[8 * p + i] = right[p][i / 4][i % 4]; }
+        sw[p] = !is_swap[p] ? 0 : (*is_swap[p] ? 2 : 1);
+    }
+    check(rsv_poseidon2_emulated(l.data(), r.data(), sw.data(), rows.data(), n, default_device()), "rsv_poseidon2_emulated");
+    std::vector<EmulatedWitness> out(n);
+    for (size_t p = 0; p < n; p++) {
+        auto row = [&](int k) { const uint32_t* q = &rows[((size_t)RSV_EMU_STRIDE * p + k) * 4]; return QM31{q[0], q[1], q[2], q[3]}; };
+        if (is_swap[p]) for (int k = 0; k < RSV_EMU_SWAP_ROWS; k++) out[p].swap_rows.push_back(row(k));
+        for (int k = RSV_EMU_SWAP_ROWS; k < RSV_EMU_ROWS; k++) out[p].rows.push_back(row(k));
+        out[p].out_left = {row(RSV_EMU_ROWS - 4), row(RSV_EMU_ROWS - 3)};
+        out[p].out_right = {row(RSV_EMU_ROWS - 2), row(RSV_EMU_ROWS - 1)};
+    }
+    return out;
+}
+// pub fn poseidon_permute_emulated(left, right, is_swap) -> (Poseidon2HalfEmulatedVar, Poseidon2HalfEmulatedVar)
+inline EmulatedWitness poseidon_permute_emulated(const std::array<QM31, 2>& left, const std::array<QM31, 2>& right, IsSwap is_swap) {
+    return poseidon_permute_emulated_batch({left}, {right}, {is_swap})[0];
+}
+}  // namespace poseidon31::emulated
 
 // Poseidon31MerkleHasherVar (primitives/merkle/src/lib.rs)
 struct Poseidon31MerkleHasherVar {

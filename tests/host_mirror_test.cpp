@@ -35,6 +35,32 @@ static void test_poseidon2_permute() {
     EXPECT(state == want);
 }
 
+// primitives/poseidon31/src/emulated.rs:236-275: the three permutes of the reference's test through the gate-level
+// form; the returned halves are the known answer, 401 rows (+12 with a swap bit) are appended per call.
+static void test_poseidon2_emulated_permute() {
+    const std::array<M31, 16> want = {260776483, 1182896747, 1656699352, 746018898, 102875940, 1812541025, 515874083,
+                                      755063943, 1682438524, 1265420601, 238640995, 200799880, 1659717477, 2080202267,
+                                      1269806256, 1287849264};
+    const std::array<QM31, 2> lo = {QM31{0, 1, 2, 3}, QM31{4, 5, 6, 7}}, hi = {QM31{8, 9, 10, 11}, QM31{12, 13, 14, 15}};
+    using poseidon31::emulated::IsSwap;
+    auto res = poseidon31::emulated::poseidon_permute_emulated_batch({lo, lo, hi}, {hi, hi, lo}, {IsSwap{}, IsSwap{false}, IsSwap{true}});
+    EXPECT(res.size() == 3);
+    for (size_t p = 0; p < 3; p++) {
+        std::array<M31, 16> got{};
+        for (int i = 0; i < 4; i++) {
+            got[i] = res[p].out_left[0][i]; got[4 + i] = res[p].out_left[1][i];
+            got[8 + i] = res[p].out_right[0][i]; got[12 + i] = res[p].out_right[1][i];
+        }
+        EXPECT(got == want);
+        EXPECT(res[p].rows.size() == 401);
+        EXPECT(res[p].swap_rows.size() == (p == 0 ? 0u : 12u));
+    }
+    // Some((true, _)) exchanges the halves: the last swap row, new_right_1 = right_1 - (right_1 - left_1), is left_1
+    EXPECT((res[2].swap_rows[11] == QM31{12, 13, 14, 15}));
+    auto one = poseidon31::emulated::poseidon_permute_emulated(lo, hi, std::nullopt);
+    EXPECT(one.rows == res[0].rows);
+}
+
 static void test_merkle_consistency() {
     // hash_m31_columns_get_rate == Poseidon31MerkleHasher::hash_node(None, cols)
     for (size_t len : {7u, 13u, 16u, 17u, 21u, 25u}) {
@@ -151,6 +177,7 @@ int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "tests/golden/proofs";
     auto small = read_file(dir + "/small_proof.bin");
     test_poseidon2_permute();
+    test_poseidon2_emulated_permute();
     test_merkle_consistency();
     test_channel(small);
     test_fiat_shamir(small);

@@ -56,6 +56,8 @@ def test_bench_single_gpu_line():
     v = d["valu"]
     assert 0 < v["frac_of_ceiling"] <= 1.0 and 0 < v["pipeline_frac_of_ceiling"] <= 1.0
     assert v["ceiling_perms_per_s"] > v["poseidon2_perms_per_s"] > 1e9
+    e = d["emulated_poseidon2"]
+    assert e["bound"] == "hbm" and 0 < e["frac"] <= 1.0 and e["algorithmic_bytes_per_perm"] == 65 + 416 * 16
 
 
 @pytest.mark.gpu
