@@ -126,8 +126,10 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
 }
 
 // ------------------------------------------------------------------- k_scan
-// Every field element of a proof must be a canonical M31 word (< P); the only
-// words exempt are the two halves of the proof-of-work nonce.  One wave per
+// Every field element of a proof must be a canonical M31 word (< P).  Exempt are the words that are not field
+// elements and that nothing else constrains: the two halves of the proof-of-work nonce, and the proof's final word,
+// last_layer_poly.log_size — the reference never reads it (it takes the size from coeffs.len(),
+// components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any u32 there verifies.  One wave per
 // proof reads the proof once with 16-byte coalesced loads — this pass is the
 // "proof bytes read once" leg of the HBM roofline.
 __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
@@ -137,12 +139,13 @@ __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, 
     ProofMeta& m = metas[wave];
     if (m.reason != R_OK) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[wave]);
-    uint32_t nw = m.n_words, nonce = m.nonce_off;
+    const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
+    auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
     uint32_t bad = 0;
     // align the vector loop to 16 bytes
     uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
     head = umin(head, nw);
-    if (lane < head) bad |= (w[lane] >= P) && lane != nonce && lane != nonce + 1;
+    if (lane < head) bad |= (w[lane] >= P) && !exempt(lane);
     const uint4* v = reinterpret_cast<const uint4*>(w + head);
     uint32_t nv = (nw - head) >> 2;
     for (uint32_t i = lane; i < nv; i += 64) {
@@ -151,11 +154,11 @@ __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, 
         uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
         if (o) {
             for (int k = 0; k < 4; k++)
-                if (((o >> k) & 1) && base + k != nonce && base + k != nonce + 1) bad = 1;
+                if (((o >> k) & 1) && !exempt(base + k)) bad = 1;
         }
     }
     uint32_t tail = head + 4 * nv;
-    if (tail + lane < nw) bad |= (w[tail + lane] >= P) && (tail + lane) != nonce && (tail + lane) != nonce + 1;
+    if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
     if (__any(bad) && lane == 0) m.reason = R_PARSE;
 }
 

@@ -12,6 +12,20 @@ def mutants_of(proof: bytes, rng, n_random: int):
             b = bytearray(proof)
             b[4 * pos:4 * pos + 8] = int(val).to_bytes(8, "little")
             batch.append(bytes(b))
+    # non-canonical words: the word right behind every length prefix (a field element or a hash word wherever the
+    # sequence is not empty: both sides must say PARSE) and the proof's final word, last_layer_poly.log_size, which the
+    # reference never reads (any value verifies)
+    words = np.frombuffer(proof, np.uint32)
+    for pos, n, _ in ob.proof_layout(proof)["prefixes"]:
+        if n and pos + 2 < len(words):
+            for val in (0x7FFFFFFF, 0xFFFFFFFF):
+                w = words.copy()
+                w[pos + 2] = val
+                batch.append(w.tobytes())
+    for val in (0, 9, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF):
+        w = words.copy()
+        w[-1] = val
+        batch.append(w.tobytes())
     for k in range(n_random):
         b = bytearray(proof)
         for _ in range(1 + k % 5):

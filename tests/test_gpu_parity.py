@@ -72,6 +72,29 @@ def test_half_permute_known_answer_with_swap(rsv):
         assert np.concatenate([rate[0], cap[0]]).tolist() == kat
 
 
+def test_last_layer_log_size_word_is_not_a_field_element(rsv):
+    """The proof's final word, last_layer_poly.log_size, is never read by the reference (it takes the size from
+    coeffs.len(), components/hints/src/folding.rs:573): any u32 there, canonical or not, leaves the verdict alone.
+    (Found by the extended soak: the canonicity scan used to call such a proof PARSE.)"""
+    inputs_of = {e["file"]: entry_inputs(e) for e in load_manifest()}
+    for name in ("small_proof.bin", "recursive_proof_16_15.bin"):
+        proof = read_proof(name)
+        cfg = fixture_cfg(name)
+        batch = []
+        for val in (0, 9, P - 1, P, 0x80000008, 0xFFFFFFFF):
+            w = np.frombuffer(proof, np.uint32).copy()
+            w[-1] = val
+            batch.append(w.tobytes())
+        # ... while the word before it (the last coefficient) is a field element
+        w = np.frombuffer(proof, np.uint32).copy()
+        w[-2] = P
+        batch.append(w.tobytes())
+        acc, reason = rsv.verify_batch(batch, cfg, inputs_of[name])
+        oacc, oreason = ob.verify_batch(batch, cfg, inputs_of[name])
+        assert acc.tolist() == oacc.tolist() == [1] * 6 + [0]
+        assert reason.tolist() == oreason.tolist() and reason[-1] == 1
+
+
 # ---------------------------------------------------------------------------------------------- f4: emulated Poseidon2
 def test_emulated_reference_test_on_gpu(rsv):
     """primitives/poseidon31/src/emulated.rs:236-275 with the GPU's rows: the three permutes of the reference's test

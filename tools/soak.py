@@ -1,5 +1,5 @@
 """One-off soak: GPU verdict / reason against the oracle over a large mutant corpus of every Poseidon-channel fixture
-(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random]"""
+(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed]"""
 import json
 import os
 import sys
@@ -20,7 +20,8 @@ rsv = rsvload.load_package()
 def main():
     n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["proofs"]
-    rng = np.random.default_rng(2026)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    rng = np.random.default_rng(seed)
     batch, cfgs = [], []
     for e in man:
         if [(i, tuple(v)) for i, v in e["inputs"]] != list(ob.STANDARD_INPUTS):
