@@ -720,6 +720,41 @@ def test_mutant_corpus_matches_oracle(rsv, manifest):
     assert int(acc.sum()) >= 6
 
 
+def test_mutants_behind_the_proof_of_work_match_oracle(rsv):
+    """With the real pow_bits every mutant of a transcript-absorbed section stops at the proof of work.  Here the
+    fixtures carry pow_bits = 0 in their header and are verified under pow_bits = 0 (everything else as in the reference's
+    literals), so corrupted commitments, sampled values, FRI commitments and last-layer coefficients reach the logup
+    and composition checks and — with query positions that no longer match the decommitments — the plan, Merkle and
+    FRI kernels.  Verdict and reason == oracle's; reasons 3 and 4 must actually occur."""
+    from tests.conftest import Cfg
+    rng = np.random.default_rng(17)
+    batch, cfgs = [], []
+    for name in ("recursive_proof_16_15.bin", "level1-5.bin", "level6-1.bin", "level12-1.bin"):
+        w = np.frombuffer(read_proof(name), np.uint32).copy()
+        w[10] = 0  # W_POW_BITS
+        proof = w.tobytes()
+        c = fixture_cfg(name)
+        cfg0 = Cfg(0, c.log_blowup_factor, c.log_last_layer_degree_bound, c.n_queries)
+        n_head = 4 * ob.proof_layout(proof)["nonce_word"]  # everything in front of the nonce is absorbed by the transcript
+        mut = [proof]
+        for k in range(220):
+            b = bytearray(proof)
+            for _ in range(1 + k % 3):
+                # k % 4 == 1: the first two commitments (mixed before z and alpha are drawn -> logup); k odd: the
+                # transcript-absorbed front part; k even: anywhere
+                pos = int(rng.integers(68, 132)) if k % 4 == 1 else int(rng.integers(68, n_head)) if k % 2 else int(rng.integers(0, len(b)))
+                b[pos] = int(rng.integers(0, 256))
+            mut.append(bytes(b))
+        batch += mut
+        cfgs += [cfg0] * len(mut)
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    diff = np.nonzero((acc != oacc) | (reason != oreason))[0]
+    assert diff.size == 0, [(int(i), int(reason[i]), int(oreason[i])) for i in diff[:10]]
+    counts = np.bincount(reason, minlength=13)
+    assert int(acc.sum()) >= 4 and counts[2] == 0 and counts[3] > 0 and counts[4] > 0 and counts[6:12].sum() > 0
+
+
 def test_field_ops_match_oracle(rsv):
     """Rows a1/a2 on their own: every RSV_F_* operation on 2^16 random elements plus edge values == oracle."""
     rng = np.random.default_rng(21)

@@ -1,5 +1,10 @@
 """One-off soak: GPU verdict / reason against the oracle over a large mutant corpus of every Poseidon-channel fixture
-(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed]"""
+(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed] [pow0]
+
+pow0: every fixture's pow_bits header word is set to 0 and it is verified under pow_bits = 0, so that mutants of the
+transcript-absorbed sections (commitments, sampled values, FRI layer commitments, last-layer polynomial) are not all
+stopped by the proof of work: they reach the logup / composition checks, and — with query positions that no longer
+match the decommitments — the plan, Merkle and FRI kernels."""
 import json
 import os
 import sys
@@ -22,11 +27,17 @@ def main():
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["proofs"]
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
     rng = np.random.default_rng(seed)
+    pow0 = len(sys.argv) > 3 and sys.argv[3] == "pow0"
     batch, cfgs = [], []
     for e in man:
         if [(i, tuple(v)) for i, v in e["inputs"]] != list(ob.STANDARD_INPUTS):
             continue
         proof = open(os.path.join(ROOT, "tests", "golden", "proofs", e["file"]), "rb").read()
+        if pow0:
+            w = np.frombuffer(proof, np.uint32).copy()
+            w[10] = 0  # W_POW_BITS
+            proof = w.tobytes()
+            e = dict(e, pow_bits=0)
         mut = mutants_of(proof, rng, n_random) + [proof]
         batch += mut
         # the reference's configuration literal of the fixture each mutant derives from (never the mutant's own header)
