@@ -143,8 +143,8 @@ def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
 # Instruction-cost ceiling of the permutation on one MI355X: the dynamic VALU mix of one wave-level call of
 # rsv::poseidon2() (64 permutations) priced with the per-instruction issue costs measured by tools/valu_lab.hip at
 # 4 waves/SIMD.  Derivation, class table and the PMC cross-check: tools/perm_ceiling.py (same numbers) and DESIGN §4.
-PERM_MIX = [("fast", 2314, 2.50), ("v_min_u32", 442, 4.27), ("v_mad_u64_u32", 526, 4.54), ("v_lshl_add_u64", 410, 4.48),
-            ("v_mad_u64_u32+addend", 736, 5.10)]
+PERM_MIX = [("fast", 2456, 2.50), ("v_min_u32", 442, 4.27), ("v_mad_u64_u32", 526, 4.54), ("v_lshl_add_u64", 410, 4.48),
+            ("v_mad_u64_u32+addend", 564, 5.10)]
 SIMDS, LAB_GHZ = 1024, 2.4
 
 

@@ -2,6 +2,14 @@
 #pragma once
 #include "k_query.hpp"
 
+// waves per SIMD the Merkle kernels are compiled for (register budget 512 / waves, in granules of 8)
+#ifndef RSV_PAIR_WAVES
+#define RSV_PAIR_WAVES 5
+#endif
+#ifndef RSV_TRACE_WAVES
+#define RSV_TRACE_WAVES 6
+#endif
+
 namespace rsv {
 
 // --------------------------------------------------------------- k_row_hash
@@ -164,7 +172,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_trace_merkle(Fused<MerkleArgs> f) {
+__global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<MerkleArgs> f) {
     RSV_TAG(3);
     RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];
@@ -295,12 +303,15 @@ __global__ __launch_bounds__(BLOCK) void k_trace_merkle(Fused<MerkleArgs> f) {
 // blockIdx.y = 0 is the FRI first-layer tree (one QM31 column at each distinct
 // column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pair_merkle(Fused<MerkleArgs> f) {
+__global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<MerkleArgs> f) {
     RSV_TAG(4);
     RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
     __shared__ uint32_t xcol[BLOCK][8];     // phase B (nodes with their column folded in), data levels only
-    __shared__ uint32_t xch2[BLOCK][8];     // path emission only: pre-column node hashes at data levels
+    // path emission only: pre-column node hashes at data levels.  Dynamic LDS (BLOCK x 32 bytes, passed by the launch
+    // only when pair paths are emitted): without it the kernel holds 29 KB of LDS and five workgroups fit a CU.
+    extern __shared__ uint32_t xch2_dyn[];
+    uint32_t (*xch2)[8] = reinterpret_cast<uint32_t (*)[8]>(xch2_dyn);
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed[2];

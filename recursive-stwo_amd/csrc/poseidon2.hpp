@@ -22,31 +22,36 @@ struct State16 {
     uint32_t s[16];
 };
 
-__constant__ __attribute__((aligned(64))) uint32_t RC_FULL[8][16] = {
-    {0x768bab52, 0x70e0ab7d, 0x3d266c8a, 0x6da42045, 0x600fef22, 0x41dace6b, 0x64f9bdd4, 0x5d42d4fe,
-     0x76b1516d, 0x6fc9a717, 0x70ac4fb6, 0x00194ef6, 0x22b644e2, 0x1f7916d5, 0x47581be2, 0x2710a123},
-    {0x6284e867, 0x018d3afe, 0x5df99ef3, 0x4c1e467b, 0x566f6abc, 0x2994e427, 0x538a6d42, 0x5d7bf2cf,
-     0x7fda2dab, 0x0fd854c4, 0x46922fca, 0x3d7763a1, 0x19fd05ca, 0x0a4bbb43, 0x15075851, 0x3d903d76},
-    {0x2d290ff7, 0x40809fa0, 0x59dac6ec, 0x127927a2, 0x6bbf0ea0, 0x0294140f, 0x24742976, 0x6e84c081,
-     0x22484f4a, 0x354cae59, 0x0453ffe1, 0x3f47a3cc, 0x0088204e, 0x6066e109, 0x3b7c4b80, 0x6b55665d},
-    {0x3bc4b897, 0x735bf378, 0x508daf42, 0x1884fc2b, 0x7214f24c, 0x7498be0a, 0x1a60e640, 0x3303f928,
-     0x29b46376, 0x5c96bb68, 0x65d097a5, 0x1d358e9f, 0x4a9a9017, 0x4724cf76, 0x347af70f, 0x1e77e59a},
-    {0x57090613, 0x1fa42108, 0x17bbef50, 0x1ff7e11c, 0x047b24ca, 0x4e140275, 0x4fa086f5, 0x079b309c,
-     0x1159bd47, 0x6d37e4e5, 0x075d8dce, 0x12121ca0, 0x7f6a7c40, 0x68e182ba, 0x5493201b, 0x0444a80e},
-    {0x0064f4c6, 0x6467abe6, 0x66975762, 0x2af68f9b, 0x345b33be, 0x1b70d47f, 0x053db717, 0x381189cb,
-     0x43b915f8, 0x20df3694, 0x0f459d26, 0x77a0e97b, 0x2f73e739, 0x1876c2f9, 0x65a0e29a, 0x4cabefbe},
-    {0x5abd1268, 0x4d34a760, 0x12771799, 0x69a0c9ac, 0x39091e55, 0x7f611cd0, 0x3af055da, 0x7ac0bbdf,
-     0x6e0f3a24, 0x41e3b6f7, 0x49b3756d, 0x568bc538, 0x20c079d8, 0x1701c72c, 0x7670dc6c, 0x5a439035},
-    {0x7c93e00e, 0x561fbb4d, 0x1178907b, 0x02737406, 0x32fb24f1, 0x6323b60a, 0x6ab12418, 0x42c99cea,
-     0x155a0b97, 0x53d1c6aa, 0x2bd20347, 0x279b3d73, 0x4f5f3c70, 0x0245af6c, 0x238359d3, 0x49966a59}};
+#define RSV_RC_FULL_INIT { \
+    {0x768bab52, 0x70e0ab7d, 0x3d266c8a, 0x6da42045, 0x600fef22, 0x41dace6b, 0x64f9bdd4, 0x5d42d4fe, \
+     0x76b1516d, 0x6fc9a717, 0x70ac4fb6, 0x00194ef6, 0x22b644e2, 0x1f7916d5, 0x47581be2, 0x2710a123}, \
+    {0x6284e867, 0x018d3afe, 0x5df99ef3, 0x4c1e467b, 0x566f6abc, 0x2994e427, 0x538a6d42, 0x5d7bf2cf, \
+     0x7fda2dab, 0x0fd854c4, 0x46922fca, 0x3d7763a1, 0x19fd05ca, 0x0a4bbb43, 0x15075851, 0x3d903d76}, \
+    {0x2d290ff7, 0x40809fa0, 0x59dac6ec, 0x127927a2, 0x6bbf0ea0, 0x0294140f, 0x24742976, 0x6e84c081, \
+     0x22484f4a, 0x354cae59, 0x0453ffe1, 0x3f47a3cc, 0x0088204e, 0x6066e109, 0x3b7c4b80, 0x6b55665d}, \
+    {0x3bc4b897, 0x735bf378, 0x508daf42, 0x1884fc2b, 0x7214f24c, 0x7498be0a, 0x1a60e640, 0x3303f928, \
+     0x29b46376, 0x5c96bb68, 0x65d097a5, 0x1d358e9f, 0x4a9a9017, 0x4724cf76, 0x347af70f, 0x1e77e59a}, \
+    {0x57090613, 0x1fa42108, 0x17bbef50, 0x1ff7e11c, 0x047b24ca, 0x4e140275, 0x4fa086f5, 0x079b309c, \
+     0x1159bd47, 0x6d37e4e5, 0x075d8dce, 0x12121ca0, 0x7f6a7c40, 0x68e182ba, 0x5493201b, 0x0444a80e}, \
+    {0x0064f4c6, 0x6467abe6, 0x66975762, 0x2af68f9b, 0x345b33be, 0x1b70d47f, 0x053db717, 0x381189cb, \
+     0x43b915f8, 0x20df3694, 0x0f459d26, 0x77a0e97b, 0x2f73e739, 0x1876c2f9, 0x65a0e29a, 0x4cabefbe}, \
+    {0x5abd1268, 0x4d34a760, 0x12771799, 0x69a0c9ac, 0x39091e55, 0x7f611cd0, 0x3af055da, 0x7ac0bbdf, \
+     0x6e0f3a24, 0x41e3b6f7, 0x49b3756d, 0x568bc538, 0x20c079d8, 0x1701c72c, 0x7670dc6c, 0x5a439035}, \
+    {0x7c93e00e, 0x561fbb4d, 0x1178907b, 0x02737406, 0x32fb24f1, 0x6323b60a, 0x6ab12418, 0x42c99cea, \
+     0x155a0b97, 0x53d1c6aa, 0x2bd20347, 0x279b3d73, 0x4f5f3c70, 0x0245af6c, 0x238359d3, 0x49966a59}}
+__constant__ __attribute__((aligned(64))) uint32_t RC_FULL[8][16] = RSV_RC_FULL_INIT;
+constexpr uint32_t RC_FULL_K[8][16] = RSV_RC_FULL_INIT;  // the same values as compile-time constants (literal operands)
 
 // what the linear layer of the LAST first-half full round adds: only lane 0 gets a constant (the first partial one)
 __constant__ __attribute__((aligned(64))) uint32_t RC_FIRST_PARTIAL[16] = {0x7f7ec4bf};
 
-__constant__ __attribute__((aligned(64))) uint32_t RC_PARTIAL[16] = {  // 14 constants + 2 words of padding (block loads)
-   0x7f7ec4bf, 0x0421926f, 0x5198e669, 0x34db3148, 0x4368bafd,
-                                        0x66685c7f, 0x78d3249a, 0x60187881, 0x76dad67a, 0x0690b437,
-                                        0x1ea95311, 0x40e5369a, 0x38f103fc, 0x1d226a21, 0, 0};
+// 14 constants + 2 words of padding (block loads)
+#define RSV_RC_PARTIAL_INIT { \
+   0x7f7ec4bf, 0x0421926f, 0x5198e669, 0x34db3148, 0x4368bafd, \
+                                        0x66685c7f, 0x78d3249a, 0x60187881, 0x76dad67a, 0x0690b437, \
+                                        0x1ea95311, 0x40e5369a, 0x38f103fc, 0x1d226a21, 0, 0}
+__constant__ __attribute__((aligned(64))) uint32_t RC_PARTIAL[16] = RSV_RC_PARTIAL_INIT;
+constexpr uint32_t RC_PARTIAL_K[16] = RSV_RC_PARTIAL_INIT;
 
 // ---- straightforward canonical implementation (readable restatement; baseline of tools/perm_lab.hip)
 __device__ __forceinline__ uint32_t pow5_ref(uint32_t x) {
@@ -222,6 +227,7 @@ __device__ __forceinline__ void load_rc16(const uint32_t* p, uint32_t* dst) {
     for (int q = 0; q < 4; q++) { uint4 t4 = p4[q]; dst[4 * q] = t4.x; dst[4 * q + 1] = t4.y; dst[4 * q + 2] = t4.z; dst[4 * q + 3] = t4.w; }
 }
 
+#ifdef RSV_P2_OLD
 __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     uint64_t V[16];
     const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
@@ -302,6 +308,84 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
         s[i] = min(t, t - P);
     }
 }
+#else
+// Round constant + canonicalisation in one step.  t = fold2(V) with V the doubled accumulator of a linear layer
+// WITHOUT its round constant: t <= P + HI where HI bounds the accumulator's high word (160 after a full-round
+// layer, < 2^19 after a partial-round one).  With c = P - rc (a compile-time literal):
+//     t >= c :  t - c in [0, P - 1]  (needs c > HI; every constant of this parameter set is < P - 2^19, asserted below)
+//               and t - c + P in [P, 2P - 1]: the minimum is t - c  = t + rc - P
+//     t <  c :  t - c wraps to >= 2^32 - P > 2^31 and t - c + P = t + rc in [0, P - 1]: the minimum is t + rc
+// so min(t - c, t - c + P) is the CANONICAL t + rc mod P in two literal adds (fast class, 2.5 cycles each) and a
+// v_min — against v_mad_u64_u32 (2 * rc folded into V, 5.1) + a literal add + v_min for the unfused form.
+template <uint32_t RC>
+__device__ __forceinline__ uint32_t canon_rc(uint32_t t) {
+    static_assert(RC < P - (1u << 19), "round constant too close to P for the fused reduction");
+    constexpr uint32_t c = P - RC;
+    return min(t - c, t + (P - c));
+}
+
+template <int R, int I>
+__device__ __forceinline__ void sbox_full(const uint64_t* V, uint32_t* s) {
+    s[I] = pow5(canon_rc<RC_FULL_K[R][I]>(fold2(V[I])));
+    if constexpr (I + 1 < 16) sbox_full<R, I + 1>(V, s);
+}
+// the first full round of the second half takes its inputs already folded (from the last partial round)
+template <int I>
+__device__ __forceinline__ void sbox_full4(uint32_t* s) {
+    s[I] = pow5(canon_rc<RC_FULL_K[4][I]>(s[I]));
+    if constexpr (I + 1 < 16) sbox_full4<I + 1>(s);
+}
+
+template <int R>
+__device__ __forceinline__ void partial_round(uint32_t* s, uint32_t k2, uint32_t k6, const uint32_t* kd) {
+    uint32_t u0 = pow5(canon_rc<RC_PARTIAL_K[R]>(s[0]));                 // s[0] <= P + 2^19
+    // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
+    uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) { a = mad64(s[i], k2, a); b = mad64(s[i + 1], k2, b); }
+    uint64_t sum2 = add64(a, b);
+    // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50, so every fold is <= P + 2^18
+    s[0] = fold2(mad64(u0, k6, sum2));
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
+}
+
+__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
+    uint64_t V[16];
+    const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
+    // s: canonical input.  V never carries a round constant: the constants are literals of the fused reductions.
+    mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<0, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<1, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<2, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<3, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    // partial rounds: every lane lazily folded (<= P + 2^18), lane 0 goes through the S-box
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
+    // 2 * diag: 2^(i+2) for lanes 1..15, as opaque wave-uniform multipliers
+    uint32_t kd[16];
+    kd[0] = k6;
+#define RSV_KD(i) kd[i] = opaque(4u << (i));
+    RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
+    RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
+#undef RSV_KD
+    partial_round<0>(s, k2, k6, kd);  partial_round<1>(s, k2, k6, kd);  partial_round<2>(s, k2, k6, kd);
+    partial_round<3>(s, k2, k6, kd);  partial_round<4>(s, k2, k6, kd);  partial_round<5>(s, k2, k6, kd);
+    partial_round<6>(s, k2, k6, kd);  partial_round<7>(s, k2, k6, kd);  partial_round<8>(s, k2, k6, kd);
+    partial_round<9>(s, k2, k6, kd);  partial_round<10>(s, k2, k6, kd); partial_round<11>(s, k2, k6, kd);
+    partial_round<12>(s, k2, k6, kd); partial_round<13>(s, k2, k6, kd);
+    sbox_full4<0>(s);      mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<5, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<6, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full<7, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t t = fold2(V[i]);
+        s[i] = min(t, t - P);
+    }
+}
+#endif
 
 #ifdef RSV_COUNT_PERMS
 // Diagnostic build only (make count): executed permutations per kernel tag — [2t] active lanes, [2t+1] wave-level calls.

@@ -61,7 +61,7 @@ def main():
         f.write("# FETCH_SIZE / WRITE_SIZE are KiB as reported; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream, MI355X_MICROARCH.md)\n")
         f.write("# eff_clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / avg_ms; valu_issue_frac = SQ_INSTS_VALU / avg_ms against 1024 SIMDs x 2.4 GHz / 2 cycles\n")
         f.write("# wave_*_frac: SQ_WAIT_ANY (parked at s_waitcnt / barrier), SQ_WAIT_INST_ANY (ready but not issued: the VALU is taken by another wave) and SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; they sum to ~1\n")
-        f.write("# frac_of_perm_mix_issue_ceiling = SQ_INSTS_VALU x 3.534 cycles-at-2.4-GHz (mean issue cost of the permutation's instruction mix, tools/perm_ceiling.py) / (avg_ms x 1024 SIMDs x 2.4 GHz): meaningful for the permutation-dominated kernels only\n")
+        f.write("# frac_of_perm_mix_issue_ceiling = SQ_INSTS_VALU x 3.440 cycles-at-2.4-GHz (mean issue cost of the permutation's instruction mix, tools/perm_ceiling.py) / (avg_ms x 1024 SIMDs x 2.4 GHz): meaningful for the permutation-dominated kernels only\n")
         f.write("# counter passes serialize the dispatches: per-kernel counters are those of the kernel running ALONE, avg_ms comes from the (concurrent) kernel-trace pass\n")
         f.write("# kernels on the side stream (k_row_hash, k_query, k_oods, k_qconst, k_scan) overlap main-stream kernels: their durations and clocks are not isolated\n")
         f.write(",".join(cols) + "\n")
@@ -79,7 +79,7 @@ def main():
                                               round(c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
                                               round(c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
                                               round(c.get("SQ_ACTIVE_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
-                                              round(c.get("SQ_INSTS_VALU", 0) * 3.534 / (ms * 1e-3 * 1024 * 2.4e9), 3) if ms > 0 else 0]) + "\n")
+                                              round(c.get("SQ_INSTS_VALU", 0) * 3.440 / (ms * 1e-3 * 1024 * 2.4e9), 3) if ms > 0 else 0]) + "\n")
             short = k.replace("rsv::", "").split("<")[0]
             latest["kernels"][short] = {"avg_ms": ms, "hbm_bytes_corrected": int((2 * fetch + write) * 1024),
                                         "SQ_INSTS_VALU": int(c.get("SQ_INSTS_VALU", 0)), "eff_clock_GHz": round(clock, 3)}

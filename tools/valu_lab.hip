@@ -74,6 +74,15 @@ DEF_KERNEL(k_sub_nc, asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b
 DEF_KERNEL(k_ashr, asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i])))
 DEF_KERNEL(k_dot, asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
 
+// what hipcc emits behind an inline-asm statement whose result the next instruction reads (dst-sel forwarding hazard
+// assumed for opaque asm on gfx940+): the same instruction followed by s_nop 0
+DEF_KERNEL(k_add_nop, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 0" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_mad64_acc_nop, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n\ts_nop 0" : "+v"(w[i]) : "v"(a[i]), "v"(b) : "s10", "s11"))
+DEF_KERNEL(k_lshl_add64_nop, asm volatile("v_lshl_add_u64 %0, %0, 1, %1\n\ts_nop 0" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS])))
+// a dependent S-box-like chain: mad -> lshr -> add -> sub -> min, with and without the nops
+DEF_KERNEL(k_chain, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, 0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, 0x80000001, %1\n\tv_min_u32 %1, %1, %2" : "+v"(w[i]), "+v"(a[i]), "+v"(c) : : "s10", "s11"))
+DEF_KERNEL(k_chain_nop, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, 0\n\ts_nop 0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, 0x80000001, %1\n\tv_min_u32 %1, %1, %2\n\ts_nop 0" : "+v"(w[i]), "+v"(a[i]), "+v"(c) : : "s10", "s11"))
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Case { const char* name; kern_t k; };
 
@@ -93,7 +102,9 @@ int main(int argc, char** argv) {
                     {"v_ashrrev_i32", k_ashr}, {"v_max_u32", k_max}, {"v_min_i32", k_mini}, {"v_mov_b32", k_mov}, {"v_bfi_b32", k_bfi}, {"v_xad_u32", k_xad},
                     {"v_add_lshl_u32", k_add_lshl}, {"v_med3_u32", k_med3}, {"v_min3_u32", k_min3}, {"cmp+cndmask (2)", k_cmp_cnd},
                     {"sub_co+cndmask (2)", k_sub_co_cnd}, {"v_addc_co_u32", k_addc}, {"v_add_u32 sgpr", k_add_s}, {"v_add_u32 literal", k_add_lit},
-                    {"v_and_b32 literal", k_and_lit}, {"v_min_u32 literal", k_min_lit}, {"v_mad_u64_u32 sgpr", k_mad64_s}, {"v_mul_lo self", k_mul_lo_2dep}, {"v_mad_i32_i24", k_dot}};
+                    {"v_and_b32 literal", k_and_lit}, {"v_min_u32 literal", k_min_lit}, {"v_mad_u64_u32 sgpr", k_mad64_s}, {"v_mul_lo self", k_mul_lo_2dep}, {"v_mad_i32_i24", k_dot},
+                    {"v_add_u32 + s_nop", k_add_nop}, {"v_mad_u64_u32(acc) + s_nop", k_mad64_acc_nop}, {"v_lshl_add_u64 + s_nop", k_lshl_add64_nop},
+                    {"chain of 5", k_chain}, {"chain of 5 + 2 s_nop", k_chain_nop}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
