@@ -127,6 +127,26 @@ __device__ __forceinline__ void poseidon2_ref_inline(uint32_t* s) {
 //       L2 = [0, 2P]          (one conditional subtract away from C)
 //     Bit-exactness with the canonical reference (poseidon2_ref_inline) is tested on the GPU.
 // ===========================================================================================
+// Issue pacing.  Measured on MI355X (whole pipeline, 65 536 proofs): when a wave presents an instruction that depends
+// on its own previous VALU result, the SIMD stalls on it instead of issuing another wave's instruction.  One extra
+// wait state behind every v_mad_u64_u32 (the compiler adds one of its own behind an asm statement whose result is
+// read next) and two behind the v_min that ends a reduction take the wave out of arbitration for those cycles:
+//     no pacing 37.75 ms | mad 36.40 | mad + canon 35.80 | also behind fold2 / the doublings: 35.75-35.85 (plateau)
+//     two wait states behind the multiplies: 36.17 (worse) | s_nop 3: 40.2
+// The wait states cost nothing at >= 4 waves per SIMD (other waves fill them); at one wave per SIMD (the lane-form
+// transcript of batches > 24 576) they lengthen the chain by ~25 % — that kernel runs underneath k_row_hash.
+#ifndef RSV_PACE_MAD
+#define RSV_PACE_MAD "\n\ts_nop 0"
+#endif
+#ifndef RSV_PACE_DBL
+#define RSV_PACE_DBL ""
+#endif
+#ifndef RSV_PACE_CANON
+#define RSV_PACE_CANON 1
+#endif
+#ifndef RSV_PACE_FOLD
+#define RSV_PACE_FOLD 0
+#endif
 __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {
     uint64_t d;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -150,33 +170,45 @@ __device__ __forceinline__ uint32_t opaque(uint32_t k) {
 // x0*k + x1*k into (x0 + x1)*k, which costs a 64-bit add, a 64x32 multiply and zero-extension moves.
 __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) {
     uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b_uniform, int) {  // b in an SGPR
     uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
     return d;
 }
 __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b_uniform, uint64_t c) {  // a * b + c, b in an SGPR
     uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
     return d;
 }
 __device__ __forceinline__ uint64_t mad64u(uint32_t a_uniform, uint32_t b, uint64_t c) {  // a in an SGPR, b in a VGPR
     uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "s"(a_uniform), "v"(b), "v"(c));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "s"(a_uniform), "v"(b), "v"(c));
     return d;
 }
 __device__ __forceinline__ uint32_t dbl32(uint32_t x) {  // x + x as a fast-class add (not a shift)
     uint32_t d;
-    asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
+    asm("v_add_u32 %0, %1, %1" RSV_PACE_DBL : "=v"(d) : "v"(x));
     return d;
 }
 // V = 2v with v < 2^62  ->  (v >> 31) + (v & P)
-__device__ __forceinline__ uint32_t fold2(uint64_t V) { return (uint32_t)(V >> 32) + ((uint32_t)V >> 1); }
+__device__ __forceinline__ uint32_t fold2(uint64_t V) {
+    uint32_t r = (uint32_t)(V >> 32) + ((uint32_t)V >> 1);
+#if RSV_PACE_FOLD
+    asm volatile("s_nop 0" : "+v"(r));
+#endif
+    return r;
+}
 // t in [0, 2P] -> C
-__device__ __forceinline__ uint32_t canon(uint32_t t) { return min(t, t - P); }
+__device__ __forceinline__ uint32_t canon(uint32_t t) {
+    uint32_t r = min(t, t - P);
+#if RSV_PACE_CANON
+    asm volatile("s_nop 0" : "+v"(r));
+#endif
+    return r;
+}
 
 // x in C  ->  x^5 in L2
 __device__ __forceinline__ uint32_t pow5(uint32_t x) {
@@ -321,7 +353,11 @@ template <uint32_t RC>
 __device__ __forceinline__ uint32_t canon_rc(uint32_t t) {
     static_assert(RC < P - (1u << 19), "round constant too close to P for the fused reduction");
     constexpr uint32_t c = P - RC;
-    return min(t - c, t + (P - c));
+    uint32_t r = min(t - c, t + (P - c));
+#if RSV_PACE_CANON
+    asm volatile("s_nop 0" : "+v"(r));
+#endif
+    return r;
 }
 
 template <int R, int I>
