@@ -83,6 +83,33 @@ DEF_KERNEL(k_lshl_add64_nop, asm volatile("v_lshl_add_u64 %0, %0, 1, %1\n\ts_nop
 DEF_KERNEL(k_chain, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, 0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, 0x80000001, %1\n\tv_min_u32 %1, %1, %2" : "+v"(w[i]), "+v"(a[i]), "+v"(c) : : "s10", "s11"))
 DEF_KERNEL(k_chain_nop, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, 0\n\ts_nop 0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, 0x80000001, %1\n\tv_min_u32 %1, %1, %2\n\ts_nop 0" : "+v"(w[i]), "+v"(a[i]), "+v"(c) : : "s10", "s11"))
 
+// ---- fully DEPENDENT chains (one chain per wave): what a wave costs the SIMD when every instruction reads the result
+// of the one before it, with and without wait states in between.  Costs are per VALU instruction (nops not counted).
+#define DEF_DEP(NAME, BODY)                                                                          \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {                      \
+        uint32_t a = threadIdx.x * 2654435761u + seed, b = seed | 1u;                                \
+        uint64_t w = a;                                                                              \
+        for (int it = 0; it < ITERS; it++) {                                                         \
+            _Pragma("unroll") for (int i = 0; i < CHAINS; i++) { BODY; }                             \
+        }                                                                                            \
+        if ((a ^ (uint32_t)w ^ (uint32_t)(w >> 32)) == 0x12345678u) out[0] = a;                      \
+    }
+DEF_DEP(d_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)))
+DEF_DEP(d_add_n0, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 0" : "+v"(a) : "v"(b)))
+DEF_DEP(d_add_n1, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 1" : "+v"(a) : "v"(b)))
+DEF_DEP(d_add_n3, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 3" : "+v"(a) : "v"(b)))
+DEF_DEP(d_min, asm volatile("v_min_u32 %0, %0, %1" : "+v"(a) : "v"(b)))
+DEF_DEP(d_min_n0, asm volatile("v_min_u32 %0, %0, %1\n\ts_nop 0" : "+v"(a) : "v"(b)))
+DEF_DEP(d_min_n1, asm volatile("v_min_u32 %0, %0, %1\n\ts_nop 1" : "+v"(a) : "v"(b)))
+DEF_DEP(d_mad, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, %0" : "+v"(w) : "v"(b) : "s10", "s11"))
+DEF_DEP(d_mad_n0, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\ts_nop 0" : "+v"(w) : "v"(b) : "s10", "s11"))
+DEF_DEP(d_mad_n1, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\ts_nop 1" : "+v"(w) : "v"(b) : "s10", "s11"))
+DEF_DEP(d_mad_n3, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\ts_nop 3" : "+v"(w) : "v"(b) : "s10", "s11"))
+// add -> mad -> (64-bit add as the consumer of the product) -> back to add through a 64-bit operand
+DEF_DEP(d_mix, asm volatile("v_add_u32 %1, %1, %2\n\tv_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\tv_lshl_add_u64 %0, %0, 1, %0" : "+v"(w), "+v"(a) : "v"(b) : "s10", "s11"))
+DEF_DEP(d_mix_n0, asm volatile("v_add_u32 %1, %1, %2\n\ts_nop 0\n\tv_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\ts_nop 0\n\tv_lshl_add_u64 %0, %0, 1, %0\n\ts_nop 0" : "+v"(w), "+v"(a) : "v"(b) : "s10", "s11"))
+DEF_DEP(d_mix_n1, asm volatile("v_add_u32 %1, %1, %2\n\ts_nop 1\n\tv_mad_u64_u32 %0, s[10:11], %1, %1, %0\n\ts_nop 1\n\tv_lshl_add_u64 %0, %0, 1, %0\n\ts_nop 1" : "+v"(w), "+v"(a) : "v"(b) : "s10", "s11"))
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Case { const char* name; kern_t k; };
 
@@ -104,7 +131,11 @@ int main(int argc, char** argv) {
                     {"sub_co+cndmask (2)", k_sub_co_cnd}, {"v_addc_co_u32", k_addc}, {"v_add_u32 sgpr", k_add_s}, {"v_add_u32 literal", k_add_lit},
                     {"v_and_b32 literal", k_and_lit}, {"v_min_u32 literal", k_min_lit}, {"v_mad_u64_u32 sgpr", k_mad64_s}, {"v_mul_lo self", k_mul_lo_2dep}, {"v_mad_i32_i24", k_dot},
                     {"v_add_u32 + s_nop", k_add_nop}, {"v_mad_u64_u32(acc) + s_nop", k_mad64_acc_nop}, {"v_lshl_add_u64 + s_nop", k_lshl_add64_nop},
-                    {"chain of 5", k_chain}, {"chain of 5 + 2 s_nop", k_chain_nop}};
+                    {"chain of 5", k_chain}, {"chain of 5 + 2 s_nop", k_chain_nop},
+                    {"DEP v_add_u32", d_add}, {"DEP v_add_u32 + s_nop 0", d_add_n0}, {"DEP v_add_u32 + s_nop 1", d_add_n1}, {"DEP v_add_u32 + s_nop 3", d_add_n3},
+                    {"DEP v_min_u32", d_min}, {"DEP v_min_u32 + s_nop 0", d_min_n0}, {"DEP v_min_u32 + s_nop 1", d_min_n1},
+                    {"DEP v_mad_u64_u32", d_mad}, {"DEP v_mad_u64_u32 + s_nop 0", d_mad_n0}, {"DEP v_mad_u64_u32 + s_nop 1", d_mad_n1}, {"DEP v_mad_u64_u32 + s_nop 3", d_mad_n3},
+                    {"DEP add,mad,add64 (3)", d_mix}, {"DEP add,mad,add64 + s_nop 0 each (3)", d_mix_n0}, {"DEP add,mad,add64 + s_nop 1 each (3)", d_mix_n1}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
