@@ -1,10 +1,13 @@
 """One-off soak: GPU verdict / reason against the oracle over a large mutant corpus of every Poseidon-channel fixture
-(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed] [pow0]
+(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed] [pow0|-] [single K]
 
 pow0: every fixture's pow_bits header word is set to 0 and it is verified under pow_bits = 0, so that mutants of the
 transcript-absorbed sections (commitments, sampled values, FRI layer commitments, last-layer polynomial) are not all
 stopped by the proof of work: they reach the logup / composition checks, and — with query positions that no longer
-match the decommitments — the plan, Merkle and FRI kernels."""
+match the decommitments — the plan, Merkle and FRI kernels.
+single K: additionally verify the first K proofs of the shuffled corpus ONE PER CALL (uniform-batch path, natural slot
+order, the small-batch kernel forms) and in groups of 3 under the smallest workspace budget the library accepts (64 MB).  The
+kernel-form overrides RSV_TRANSCRIPT / RSV_OODS / RSV_QCONST / RSV_PLAN of the environment apply to every call."""
 import json
 import os
 import sys
@@ -59,7 +62,22 @@ def main():
           f"reasons {np.bincount(reason, minlength=13).tolist()}; mismatches {diff.size}")
     for i in diff[:10]:
         print("  mismatch", int(i), int(acc[i]), int(reason[i]), int(oacc[i]), int(oreason[i]), len(batch[i]))
-    sys.exit(1 if diff.size else 0)
+    bad = int(diff.size)
+    if len(sys.argv) > 5 and sys.argv[4] == "single":
+        k = min(int(sys.argv[5]), len(batch))
+        one = 0
+        for i in range(k):
+            a, r = rsv.verify_batch([batch[i]], [cfgs[i]])
+            one += int(a[0] != oacc[i] or r[0] != oreason[i])
+        os.environ["RSV_WS_BUDGET_MB"] = "1"
+        three = 0
+        for i in range(0, k - 2, 3):
+            a, r = rsv.verify_batch(batch[i:i + 3], cfgs[i:i + 3])
+            three += int((a != oacc[i:i + 3]).any() or (r != oreason[i:i + 3]).any())
+        del os.environ["RSV_WS_BUDGET_MB"]
+        print(f"single: {k} one-proof calls, mismatches {one}; {k // 3} three-proof calls under the minimum workspace budget, mismatches {three}")
+        bad += one + three
+    sys.exit(1 if bad else 0)
 
 
 if __name__ == "__main__":
