@@ -93,33 +93,41 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     ProofCtx& c = ctxs[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     const bool rate = i < 8;
+    const RowRC rc = load_row_rc(i);
     uint32_t dg = 0, n_sent = 0;
     // mix: digest = perm(left || digest)[8..16]
     auto mix = [&](uint32_t left_word) {
-        uint32_t out = poseidon2_row(rate ? left_word : dg, i);
+        uint32_t out = poseidon2_row(rate ? left_word : dg, i, rc);
         if (!rate) dg = out;
         n_sent = 0;
     };
     // draw: perm([n_sent, 0 x 7] || digest)[0..8]; the digest is not advanced
     auto draw = [&]() {
-        uint32_t out = poseidon2_row(rate ? (i == 0 ? n_sent : 0u) : dg, i);
+        uint32_t out = poseidon2_row(rate ? (i == 0 ? n_sent : 0u) : dg, i, rc);
         n_sent++;
         return out;
     };
-    auto mix_words = [&](const uint32_t* src, uint32_t n_words) { mix((rate && i < n_words) ? src[i] : 0u); };
+    // Every word the chain absorbs is fetched BEFORE the permutation that precedes its use: a load issued between
+    // two permutations is consumed at once and costs the row its whole HBM latency (1-2 us, against 2-3 us for the
+    // permutation itself).
+    auto word_of = [&](const uint32_t* src, uint32_t n_words) { return (rate && i < n_words) ? src[i] : 0u; };
     auto store_felt = [&](uint32_t* dst, uint32_t out) { if (i < 4) dst[i] = out; };
+    auto sample_word = [&](int k) { return rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u; };
+    const uint32_t c0 = word_of(w + W_COMMIT0, 8), c1 = word_of(w + W_COMMIT0 + 8, 8), c2 = word_of(w + W_COMMIT0 + 16, 8);
+    const uint32_t c3 = word_of(w + W_COMMIT0 + 24, 8), sums = word_of(w + W_PLONK_SUM, 8);
+    uint32_t nxt = sample_word(0);
     uint32_t out;
-    mix_words(w + W_COMMIT0, 8);
+    mix(c0);
     mix(i == 0 ? m.lp : 0u);  // statement 0: data_structures/src/lib.rs:52-55
     mix(i == 0 ? m.lq : 0u);
-    mix_words(w + W_COMMIT0 + 8, 8);
+    mix(c1);
     out = draw();  // lookup elements z, alpha
     if (i < 4) c.z[i] = out; else if (i < 8) c.alpha[i - 4] = out;
-    mix_words(w + W_PLONK_SUM, 8);  // statement 1: the two total sums are adjacent words 2..10
-    mix_words(w + W_COMMIT0 + 16, 8);
+    mix(sums);  // statement 1: the two total sums are adjacent words 2..10
+    mix(c2);
     out = draw();
     store_felt(c.rc, out);
-    mix_words(w + W_COMMIT0 + 24, 8);
+    mix(c3);
     out = draw();
     store_felt(c.oods_t, out);
     {  // CirclePointQM31Var::from_t (primitives/circle/src/lib.rs:204-219); every lane computes it
@@ -132,27 +140,41 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
             stq(c.oods_y, q_mul(q_dbl(t), inv));
         }
     }
+    const uint32_t first_commit = word_of(w + m.first.commit_off, 8);
 #pragma unroll 1
-    for (int k = 0; k < N_SAMPLES; k += 2)  // fiat_shamir/src/lib.rs:68-75
-        mix(rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u);
+    for (int k = 0; k < N_SAMPLES; k += 2) {  // fiat_shamir/src/lib.rs:68-75
+        const uint32_t cur = nxt;
+        if (k + 2 < N_SAMPLES) nxt = sample_word(k + 2);
+        mix(cur);
+    }
     out = draw();
     store_felt(c.after, out);
-    mix_words(w + m.first.commit_off, 8);
+    // the words of the last-layer polynomial that one mix absorbs (odd tail: second felt = 0)
+    auto last_word = [&](uint32_t k) {
+        const uint32_t left = 4 * (m.last_n - k);
+        return word_of(w + m.last_off + 4 * k, left < 8 ? left : 8u);
+    };
+    nxt = m.n_inner ? word_of(w + m.inner[0].commit_off, 8) : (m.last_n ? last_word(0) : 0u);
+    mix(first_commit);
     out = draw();
     store_felt(c.fri_alpha[0], out);
 #pragma unroll 1
     for (uint32_t l = 0; l < m.n_inner; l++) {
-        mix_words(w + m.inner[l].commit_off, 8);
+        const uint32_t cur = nxt;
+        nxt = l + 1 < m.n_inner ? word_of(w + m.inner[l + 1].commit_off, 8) : (m.last_n ? last_word(0) : 0u);
+        mix(cur);
         out = draw();
         store_felt(c.fri_alpha[l + 1], out);
     }
+    const uint32_t nonce_lo = w[m.nonce_off], nonce_hi = w[m.nonce_off + 1];
 #pragma unroll 1
-    for (uint32_t k = 0; k < m.last_n; k += 2) {  // fiat_shamir/src/lib.rs:94-100 (odd tail: second felt = 0)
-        const uint32_t left = 4 * (m.last_n - k);
-        mix_words(w + m.last_off + 4 * k, left < 8 ? left : 8u);
+    for (uint32_t k = 0; k < m.last_n; k += 2) {  // fiat_shamir/src/lib.rs:94-100
+        const uint32_t cur = nxt;
+        if (k + 2 < m.last_n) nxt = last_word(k + 2);
+        mix(cur);
     }
     // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
-    const uint64_t nonce = (uint64_t)w[m.nonce_off] | ((uint64_t)w[m.nonce_off + 1] << 32);
+    const uint64_t nonce = (uint64_t)nonce_lo | ((uint64_t)nonce_hi << 32);
     mix(i == 0 ? (uint32_t)(nonce & ((1u << 22) - 1)) : i == 1 ? (uint32_t)((nonce >> 22) & ((1u << 21) - 1))
         : i == 2 ? (uint32_t)((nonce >> 43) & ((1u << 21) - 1)) : 0u);
     if (!rate) c.pow_digest[i - 8] = dg;

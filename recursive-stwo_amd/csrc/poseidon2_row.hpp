@@ -43,21 +43,51 @@ __device__ __forceinline__ uint32_t sum_row(uint32_t x) {
     return m_add(x, dpp<DPP_ROR8>(x));
 }
 
+// Round constants of one lane: RC_FULL[r][i] for the eight full rounds, fetched ONCE per kernel (a load inside the
+// round loop is consumed two instructions later and costs the wave its whole latency, eight times per permutation —
+// more than the arithmetic of the round).  The partial-round constants are literals.
+struct RowRC {
+    uint32_t f[8];
+};
+__device__ __forceinline__ RowRC load_row_rc(uint32_t i) {
+    RowRC k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.f[r] = RC_FULL[r][i];
+    return k;
+}
+
+// row_newbcast:0 — lane 0 of every row, in all 16 lanes of that row
+constexpr int DPP_BCAST0 = 0x150;
+
+// One partial round.  Only word 0 goes through the S-box, and the sum of the other fifteen does not depend on it:
+// every lane computes the S-box of the row's word 0 (broadcast), while the row all-reduce of words 1..15 and the
+// diagonal products run in its shadow; what is left behind the S-box is a shift, a select and one modular add.
+template <int R>
+__device__ __forceinline__ uint32_t partial_round_row(uint32_t x, uint32_t i, uint32_t diag) {
+    const uint32_t x0 = dpp<DPP_BCAST0>(x);
+    const uint32_t rest = sum_row(i == 0 ? 0u : x);              // words 1..15
+    const uint32_t q = m_add(m_mul(x, diag), rest);               // lanes 1..15: d_i * x_i + rest
+    const uint32_t s = pow5_ref(m_add(x0, RC_PARTIAL_K[R]));      // S-box of word 0, the same in every lane
+    // lane 0: 3 s + (s + rest) = 4 s + rest;  lane i: d_i x_i + (s + rest)
+    return m_add(i == 0 ? rest : q, i == 0 ? m_shl(s, 2) : s);
+}
+
 // x: state word (lane & 15) of this row's state.  i = lane & 15.
-__device__ inline uint32_t poseidon2_row(uint32_t x, uint32_t i) {
+__device__ __forceinline__ uint32_t poseidon2_row(uint32_t x, uint32_t i, const RowRC& k) {
     const uint32_t diag = i == 0 ? 3u : (1u << (i + 1));
     const bool odd = i & 1u;
     x = mds_row(x, odd);
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) x = mds_row(pow5_ref(m_add(x, RC_FULL[r][i])), odd);
-#pragma unroll 1
-    for (int r = 0; r < 14; r++) {
-        uint32_t s = pow5_ref(m_add(x, RC_PARTIAL[r]));
-        x = i == 0 ? s : x;
-        x = m_add(sum_row(x), m_mul(x, diag));
-    }
-#pragma unroll 1
-    for (int r = 4; r < 8; r++) x = mds_row(pow5_ref(m_add(x, RC_FULL[r][i])), odd);
+#pragma unroll
+    for (int r = 0; r < 4; r++) x = mds_row(pow5_ref(m_add(x, k.f[r])), odd);
+    x = partial_round_row<0>(x, i, diag);   x = partial_round_row<1>(x, i, diag);
+    x = partial_round_row<2>(x, i, diag);   x = partial_round_row<3>(x, i, diag);
+    x = partial_round_row<4>(x, i, diag);   x = partial_round_row<5>(x, i, diag);
+    x = partial_round_row<6>(x, i, diag);   x = partial_round_row<7>(x, i, diag);
+    x = partial_round_row<8>(x, i, diag);   x = partial_round_row<9>(x, i, diag);
+    x = partial_round_row<10>(x, i, diag);  x = partial_round_row<11>(x, i, diag);
+    x = partial_round_row<12>(x, i, diag);  x = partial_round_row<13>(x, i, diag);
+#pragma unroll
+    for (int r = 4; r < 8; r++) x = mds_row(pow5_ref(m_add(x, k.f[r])), odd);
     return x;
 }
 
