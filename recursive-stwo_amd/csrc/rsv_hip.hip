@@ -45,7 +45,9 @@ void destroy_host_pipe(HostPipe*);
 struct rsv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;  // row hashes, quotient constants, k_query, k_oods, k_scan: underneath the main stream
+    hipStream_t side = nullptr;  // row hashes, quotient constants, k_query, FRI trees: underneath the main stream
+    hipStream_t aux = nullptr;   // the front half of a small batch's transcript, next to the parser
+    hipEvent_t ev_begin = nullptr, ev_front = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr, ev_ext = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
@@ -114,6 +116,9 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming) != hipSuccess ||
@@ -133,6 +138,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -143,6 +149,9 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_query) (void)hipEventDestroy(c->ev_query);
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->host_pipe) destroy_host_pipe(c->host_pipe);
     if (c->ws) (void)hipFree(c->ws);

@@ -518,6 +518,27 @@ def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_row_transcript_in_one_piece_and_split(rsv, monkeypatch, split):
+    """The row-form transcript as one launch and as front (next to the parser, before any section offset is known) +
+    back: the same verdicts, reasons and transcript rows, also for buffers the front half has to leave alone
+    (empty, truncated inside the fixed-offset part, cut right behind it, misaligned length)."""
+    monkeypatch.setenv("RSV_TRANSCRIPT", "row")
+    monkeypatch.setenv("RSV_TRANSCRIPT_SPLIT", split)
+    proof = read_proof("recursive_proof_16_15.bin")
+    cfg = fixture_cfg("recursive_proof_16_15.bin")
+    batch = [proof, ob.tamper(proof, 3), b"", proof[:64], proof[:3576], proof[:3584], proof[:3620], proof[:len(proof) - 4],
+             proof[:50000], proof, read_proof("level6-1.bin")]
+    cfgs = [cfg] * 10 + [fixture_cfg("level6-1.bin")]
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert acc.tolist() == oacc.tolist() == [1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1]
+    assert reason.tolist() == oreason.tolist()
+    rows = rsv.transcript_batch(batch, cfgs)
+    for k in (0, 9, 10):
+        assert np.array_equal(rows[k], _row_from_raw(ob.transcript_raw(batch[k])))
+
+
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level13-1.bin"])
 def test_fri_paths_match_oracle(rsv, manifest, name):
     """per-query pair paths of every FRI tree (transcript order) emitted by the GPU == oracle's."""
