@@ -1,5 +1,5 @@
 """How many Poseidon2 permutations does each kernel execute per proof, against the oracle's count of the batched
-minimum?  Needs the diagnostic build: make -C recursive-stwo_amd/csrc count.  Usage: python tools/perm_census.py"""
+minimum?  Needs the diagnostic build: make -C recursive-stwo_amd/csrc count.  Usage: python tests/perm_census.py"""
 import ctypes
 import os
 import sys

@@ -1,5 +1,5 @@
 import sys, struct, hashlib, itertools
-sys.path.insert(0,'/root/repo/tools/sha256_channel_search'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tests/sha256_channel_search'); sys.path.insert(0,'/root/repo')
 import numpy as np
 from parse import *
 from tests import oracle_binding as ob

@@ -1,5 +1,5 @@
 """One-off soak: GPU verdict / reason against the oracle over a large mutant corpus of every Poseidon-channel fixture
-(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tools/soak.py [n_random] [seed] [pow0|-] [single K]
+(tests/mutants.py generators, several hundred random corruptions each), in mixed batches.  python tests/soak.py [n_random] [seed] [pow0|-] [single K]
 
 pow0: every fixture's pow_bits header word is set to 0 and it is verified under pow_bits = 0, so that mutants of the
 transcript-absorbed sections (commitments, sampled values, FRI layer commitments, last-layer polynomial) are not all
