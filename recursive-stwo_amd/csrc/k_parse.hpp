@@ -129,15 +129,16 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
 // Every field element of a proof must be a canonical M31 word (< P).  Exempt are the words that are not field
 // elements and that nothing else constrains: the two halves of the proof-of-work nonce, and the proof's final word,
 // last_layer_poly.log_size — the reference never reads it (it takes the size from coeffs.len(),
-// components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any u32 there verifies.  One wave per
-// proof reads the proof once with 16-byte coalesced loads — this pass is the
-// "proof bytes read once" leg of the HBM roofline.
+// components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any u32 there verifies.  A wave reads
+// one proof at a time with 16-byte coalesced loads (grid-stride over the proofs: the launcher throttles the grid) —
+// this pass is the "proof bytes read once" leg of the HBM roofline.
 __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                               uint32_t n, ProofMeta* __restrict__ metas) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n) return;
+    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t wave = wave0; wave < n; wave += n_waves) {
     ProofMeta& m = metas[wave];
-    if (m.reason != R_OK) return;
+    if (m.reason != R_OK) continue;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[wave]);
     const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
     auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, 
     uint32_t tail = head + 4 * nv;
     if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
     if (__any(bad) && lane == 0) m.reason = R_PARSE;
+    }
 }
 
 }  // namespace rsv
