@@ -518,6 +518,29 @@ def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
 
 
+@pytest.mark.parametrize("blocks", ["1", "3", "0"])
+def test_throttled_canonicity_scan(rsv, monkeypatch, blocks):
+    """The canonicity scan walks the proofs with a throttled grid on large batches (a few workgroups, grid-stride over
+    the proofs).  Forced here on a small batch — one workgroup for 150 proofs, three, and the unthrottled launch —
+    with non-canonical words at the start, in the middle and at the end of every section and in the exempt words."""
+    monkeypatch.setenv("RSV_SCAN_BLOCKS", blocks)
+    proof = read_proof("recursive_proof_16_15.bin")
+    cfg = fixture_cfg("recursive_proof_16_15.bin")
+    words = np.frombuffer(proof, np.uint32)
+    lay = ob.proof_layout(proof)
+    spots = sorted({17, 60, len(words) - 2, len(words) - 1, lay["nonce_word"], lay["nonce_word"] + 1, lay["nonce_word"] - 1,
+                    lay["nonce_word"] + 2} | {pos + 2 for pos, n, _ in lay["prefixes"] if n and pos + 2 < len(words)})
+    batch = [proof]
+    for k in range(149):
+        w = words.copy()
+        w[spots[k % len(spots)]] = 0x7FFFFFFF + (k % 3)
+        batch.append(w.tobytes())
+    acc, reason = rsv.verify_batch(batch, cfg)
+    oacc, oreason = ob.verify_batch(batch, cfg)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    assert acc[0] == 1 and 1 in reason.tolist()
+
+
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_row_transcript_in_one_piece_and_split(rsv, monkeypatch, split):
     """The row-form transcript as one launch and as front (next to the parser, before any section offset is known) +
