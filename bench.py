@@ -28,6 +28,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+# dmabuf IPC: RCCL across rank processes needs it on this driver.  Set here, before anything can initialise HIP, so
+# that ranks started by an external torchrun (the driver's form) get it as well as the ones launch_ranks() starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -105,38 +109,61 @@ def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
     return d_blob, d_offsets, plen, np.array(tam, dtype=np.int64), idx
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
-    """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores."""
+    """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores: all of them (at most
+    16 threads, one shard of the sample each), then ONE thread on a sixteenth of the sample."""
     import ctypes
     from tests import oracle_binding as ob
     threads = max(1, min(os.cpu_count() or 1, 16))
     n_sample = min(n_sample, len(offsets) - 1)
-    bounds = np.linspace(0, n_sample, threads + 1).astype(int)
     pi = ob.make_inputs(ob.STANDARD_INPUTS)
     arr = (ob.PcsConfig * len(cfg_rows))(*[ob.PcsConfig(*r) for r in cfg_rows])
     of = np.ascontiguousarray(cfg_of[:n_sample], dtype=np.uint8)
 
-    def work(t):
-        lo, hi = bounds[t], bounds[t + 1]
-        if hi <= lo:
-            return 0
-        offs = np.ascontiguousarray(offsets[lo:hi + 1], dtype=np.uint64)
-        acc = np.zeros(hi - lo, np.uint8)
-        cs = ob.CfgSet(ctypes.cast(arr, ctypes.POINTER(ob.PcsConfig)), len(cfg_rows), of[lo:hi].ctypes.data)
-        rc = ob.lib.rsvo_verify_batch(blob_host.ctypes.data_as(ob._u8p), offs.ctypes.data_as(ob._u64p), hi - lo, ctypes.byref(cs),
-                                      pi, 3, acc.ctypes.data_as(ob._u8p), None)
-        assert rc == 0
-        return int(acc.sum())
+    def run(n_run, n_threads):
+        bounds = np.linspace(0, n_run, n_threads + 1).astype(int)
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        accepted = sum(ex.map(work, range(threads)))
-    dt = time.perf_counter() - t0
+        def work(t):
+            lo, hi = bounds[t], bounds[t + 1]
+            if hi <= lo:
+                return 0
+            offs = np.ascontiguousarray(offsets[lo:hi + 1], dtype=np.uint64)
+            acc = np.zeros(hi - lo, np.uint8)
+            cs = ob.CfgSet(ctypes.cast(arr, ctypes.POINTER(ob.PcsConfig)), len(cfg_rows), of[lo:hi].ctypes.data)
+            rc = ob.lib.rsvo_verify_batch(blob_host.ctypes.data_as(ob._u8p), offs.ctypes.data_as(ob._u64p), hi - lo, ctypes.byref(cs),
+                                          pi, 3, acc.ctypes.data_as(ob._u8p), None)
+            assert rc == 0
+            return int(acc.sum())
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(n_threads) as ex:
+            accepted = sum(ex.map(work, range(n_threads)))
+        return time.perf_counter() - t0, accepted
+
+    dt, accepted = run(n_sample, threads)
+    n_one = max(1, n_sample // 16)
+    dt_one, _ = run(n_one, 1)
     # Poseidon2 permutations the oracle's batched walk spends on the genuine fixtures of this workload (untimed): the
     # unit of useful work of this path, used for the in-situ permutation rate reported next to the microbenchmark
     perms = [ob.perm_count(read_fixture(f)) for f in fixtures] if fixtures else []
     return {"value": n_sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads",
+            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads; "
+                      f"one_thread: the first {n_one} of them on 1 thread",
+            "one_thread": {"value": n_one / dt_one, "unit": "proofs/s", "cores": 1},
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "note": "oracle/rsv_oracle.c: a plain scalar C restatement of the reference algorithm (not the Rust binary, which "
+                    "cannot be built here); a reported baseline, not a tuned CPU implementation",
             "perms_per_proof": (sum(perms) / len(perms)) if perms else None}
 
 
@@ -285,6 +312,22 @@ def main():
     if sv.exchange.total_accepted() != int(job_want.sum()):
         raise SystemExit("accept count (all-reduce) mismatch")
 
+    # what the process group looked like from inside (a SCALE record should prove that N ranks on N devices took part)
+    def dev_id():
+        pr = torch.cuda.get_device_properties(dev_index)
+        return {"rank": rank, "device_index": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+                "pci_bus_id": getattr(pr, "pci_bus_id", None), "pid": os.getpid()}
+    group = {"world_size": 1, "backend": None, "devices": [dev_id()]}
+    if dist.is_initialized():
+        devs = [None] * dist.get_world_size()
+        dist.all_gather_object(devs, dev_id())
+        ver = None
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        group = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver, "devices": devs}
+
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -379,6 +422,7 @@ def main():
         del d_l, d_r, d_s, d_rows
 
     cpu = None
+    host_path = None
     sample = args.cpu_sample
     if sample != 0 and world == 1:  # the CPU baseline is a single-GPU-run figure (rank 0 at N = 1 only)
         threads = max(1, min(os.cpu_count() or 1, 16))
@@ -390,7 +434,21 @@ def main():
         rows = [rsv._cfg_key(c) for c in fcfg]
         table = sorted(set(rows))
         of = np.array([table.index(rows[k]) for k in fix_idx[:n_s]], np.uint8)
-        cpu = cpu_baseline(blob_host, d_offsets[:n_s + 1].cpu().numpy(), n_s, table, of, fixtures)
+        offs_host = d_offsets[:n_s + 1].cpu().numpy()
+        # PCIe-inclusive rate (never `value`): the same sample starting in HOST memory, one buffer per proof as the
+        # reference's callers hold them, through rsv_verify_batch_host (gather -> pinned -> DMA -> verify, pipelined)
+        views = [blob_host[int(offs_host[i]):int(offs_host[i + 1])] for i in range(n_s)]
+        hcfg = [fcfg[k] for k in fix_idx[:n_s]] if len(set(rows)) > 1 else fcfg[0]
+        ctx.verify_batch_host(views[:256], hcfg[:256] if isinstance(hcfg, list) else hcfg)  # pinned staging ring, module load
+        th = time.perf_counter()
+        hacc, _ = ctx.verify_batch_host(views, hcfg)
+        hdt = time.perf_counter() - th
+        if not np.array_equal(hacc, want[:n_s]):
+            raise SystemExit("host path: verdict mismatch")
+        host_path = {"value": n_s / hdt, "unit": "proofs/s", "GBps": int(offs_host[n_s]) / hdt / 1e9, "proofs": n_s,
+                     "note": "rsv_verify_batch_host on the cpu_baseline sample: proofs start in pageable host memory, one "
+                             "buffer each; includes the gather into pinned memory and the PCIe upload.  Never `value`."}
+        cpu = cpu_baseline(blob_host, offs_host, n_s, table, of, fixtures)
         if valu is not None and cpu.get("perms_per_proof"):
             # useful permutations (the oracle's batched-walk count) the whole pipeline retires per second and GPU, against
             # the instruction-cost ceiling of the bare permutation: the efficiency figure of this VALU-bound path
@@ -410,9 +468,9 @@ def main():
                                     "bit-exact accept map of the whole job checked on every rank",
                    "proofs_per_step": n_total * args.inflight, "proofs_rank0": n, "bytes_rank0": total_bytes, "parallelism": f"shard{world}",
                    "batches_in_flight": args.inflight,
-                   "exchange": "all_gather(accept bitmap) + all_reduce(count) per step, " + ("gloo (rehearsal)" if rehearsal else
-                               ("nccl/RCCL" if world > 1 else "none (1 rank)"))},
-        "roofline": roofline, "cpu_baseline": cpu, "valu": valu, "emulated_poseidon2": emulated,
+                   "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
+                       "gloo (rehearsal)" if rehearsal else ("nccl/RCCL" if world > 1 else "none (1 rank)")))},
+        "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "valu": valu, "emulated_poseidon2": emulated,
     }
     print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RSV_M31_P 0x7fffffffu
-#define RSV_ABI_VERSION 2
+#define RSV_ABI_VERSION 3
 
 typedef enum rsv_status {
     RSV_OK = 0,
@@ -48,7 +48,19 @@ typedef enum rsv_status {
 } rsv_status;
 
 /* Why proof i was rejected.  Order = the order in which the reference's
- * stages would panic (examples/single-proof/src/main.rs:33-82). */
+ * stages would panic (examples/single-proof/src/main.rs:33-82).
+ *
+ * Reason codes are this library's extension: the reference panics at the first failed check, so only accept / reject
+ * is pinned by its fixtures; which code a rejected proof gets is defined here and checked against this repo's oracle.
+ *
+ * KNOWN DIVERGENCE from "bit-exact accept / reject on identical bytes" (deliberate, on the safe side): every
+ * field-element word of a proof must be canonical (< 2^31-1), otherwise the proof is RSV_R_PARSE.  bincode
+ * deserialises M31(u32) unchecked and stwo's release-mode arithmetic reduces such a word (partial_reduce maps P to
+ * 0), so the Rust verifier most likely ACCEPTS a genuine proof in which a 0 word has been re-encoded as P
+ * (0x7fffffff), and panics on overflow in debug builds for larger words; this library rejects all of them.  No
+ * reference fixture contains such a word, and without a Rust toolchain the reference's behaviour on one cannot be
+ * observed here.  Exempt (not field elements, read by nothing else): the two halves of the 64-bit proof-of-work
+ * nonce and the proof's final word, last_layer_poly.log_size. */
 typedef enum rsv_reason {
     RSV_R_OK = 0,
     RSV_R_PARSE = 1,        /* bincode shape / config mismatch (examples/single-proof/src/main.rs:24-31) */
@@ -118,6 +130,29 @@ void* rsv_ctx_stream(rsv_ctx* ctx);
  * Neither blocks the host. */
 int rsv_ctx_wait_stream(rsv_ctx* ctx, void* hip_stream);
 int rsv_stream_wait_ctx(rsv_ctx* ctx, void* hip_stream);
+
+/* Tuning / diagnostic knobs.  The library never reads the environment: a knob changes only through this call, on one
+ * context, or — ctx == NULL — as the process default that contexts created LATER inherit (the host-pointer
+ * convenience entry points create a context of their own, so that is how the tests steer them).  Every knob only
+ * selects between kernel forms / launch layouts that give bit-identical verdicts (the parity tests run each of them
+ * against the oracle); 0 is always "automatic" (= what production runs).  Returns RSV_E_SIZE for an unknown option,
+ * RSV_E_RANGE for a value outside the listed range. */
+typedef enum rsv_option {
+    RSV_OPT_TRANSCRIPT_FORM = 1,  /* 0 auto (by batch size), 1 one proof per 16-lane DPP row, 2 one proof per lane */
+    RSV_OPT_TRANSCRIPT_SPLIT = 2, /* 0 auto, 1 one launch, 2 front half beside the parser + back half (row form only) */
+    RSV_OPT_OODS_FORM = 3,        /* 0 auto, 1 row, 2 lane */
+    RSV_OPT_QCONST_FORM = 4,      /* 0 auto, 1 row, 2 lane */
+    RSV_OPT_PLAN_FORM = 5,        /* 0 / 1 one lane per (proof, query), 2 one lane per proof */
+    RSV_OPT_TREE_CAP = 6,         /* 0 / 1 dense top-of-tree cap, 2 every lane walks its path to the root */
+    RSV_OPT_OVERLAP_TREES = 7,    /* 0 auto, 1 FRI trees beside the trace trees (single-group batches), 2 behind them */
+    RSV_OPT_WS_BUDGET_MB = 8,     /* 1 .. 2^20: budget of the per-query workspace (default 8192); larger batches are cut into groups */
+    RSV_OPT_PERM_WG_PER_CU = 9,   /* 1 .. 8: grid of the persistent rsv_poseidon2_permute kernel (default 8) */
+    RSV_OPT_HOST_CHUNK_MB = 10,   /* 1 .. 16384: staging chunk of rsv_verify_batch_host (default 256) */
+    RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 8), else 1 .. 64 gather threads of rsv_verify_batch_host */
+    RSV_OPT_DEBUG_LOG = 12,       /* 0 / 1: print failing HIP calls to stderr (process-wide, ctx ignored) */
+    RSV_OPT_CRITICAL_CHAIN = 13   /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
+} rsv_option;
+int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 
 /* ---- a3: Poseidon2-M31 width-16 permutation -------------------------------
  * Replaces poseidon2_permute (primitives/poseidon31/src/implementation.rs:108-149).
@@ -265,8 +300,8 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
 
 /* Proofs that start in HOST memory, as the reference's callers hold them: one serialized buffer per proof
  * (bincode::serialize(&proof) -> Vec<u8>, examples/multi-proofs/src/main.rs:69-139).  Chunks of about
- * RSV_HOST_CHUNK_MB (env, default 256) MB are gathered into pinned staging memory by worker threads
- * (RSV_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
+ * RSV_OPT_HOST_CHUNK_MB (default 256) MB are gathered into pinned staging memory by worker threads
+ * (RSV_OPT_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
  * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  A buffer whose length is not a
  * multiple of 4 (every proof of this type is a whole number of 32-bit words) or exceeds 32 MB (a well-formed proof is
  * below 8 MB) is not uploaded and gets RSV_R_PARSE, like any other malformed proof. */
@@ -328,7 +363,33 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  *                                           their circle-to-line folds (folding/src/lib.rs:57-90); the value entering
  *                                           inner layer i, i < n_inner (:135-144); the value entering the last-layer
  *                                           check and the last-layer polynomial evaluated at the query's point (:194-204)
- * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE. */
+ *                                           (the library zeroes this buffer first: absent groups and the rows of rejected
+ *                                           proofs are zero)
+ * Path outputs need a uniform batch of the declared shape (n_queries >= 4, max_log, n_inner), else RSV_E_SIZE.
+ *
+ * SURVEY 8f.1, second half — the value side of the recursion circuit's Poseidon accelerator:
+ *   d_flow       [n][flow_stride][32]  PoseidonFlow (constraint_system/src/plonk_with_poseidon.rs:36,117-128,468-519) of
+ *                                      the circuit that verifies proof i: one record per Poseidon2HalfVar::permute
+ *                                      invocation (primitives/poseidon31/src/lib.rs:282-423) = the hash words of the four
+ *                                      PoseidonEntry: left8 | right8 (the inputs as given; the accelerator applies
+ *                                      the swap) | out_rate8 | out_cap8 — one 128-byte line per record; 16-byte aligned
+ *   d_flow_swap  [n][flow_stride]      SwapOption::swap of the record (bytes; both or neither with d_flow)
+ *   d_flow_count [n]                   optional: records of proof i = rsv_poseidon_flow_count of its shape; 0 when the
+ *                                      parser rejected it or flow_stride is too small for it (nothing is written then)
+ *   flow_stride                        records the caller allocated per proof
+ * Record order = the circuit's invocation order (examples/multi-proofs/src/main.rs:69-139): every channel operation of
+ * FiatShamirResults::compute (including the ceil(n_queries / 4) query draws the circuit makes where ceil(n_queries / 8)
+ * hold every query); then, for each of the four commitment trees, one SinglePathMerkleProofVar::verify per query in
+ * TRANSCRIPT query order (components/recursive/answer/src/lib.rs:214-258, data_structures/src/lib.rs:315-354); then one
+ * SinglePairMerkleProofVar::verify per query for the first FRI layer and for every inner layer
+ * (folding/src/lib.rs:23-33,186-189, data_structures/src/lib.rs:400-464).  What a next-level prover pads to a multiple of
+ * 16 and proves as its Poseidon component (six trace rows per record).  Any mix of shapes; the records of a proof
+ * that is rejected behind the parser are whatever its (failing) verification computed.  With d_flow the per-query
+ * kernels walk every path to the root themselves (no shared top-of-tree cap, no shared row hashes), like the circuit.
+ * PINNED by the reference only through the count (the padded flow of level K's verification is level K+1's Poseidon
+ * trace, whose log size is in that fixture's header: tests/test_oracle.py); the values are checked against this
+ * repo's restatement of the per-path verifiers and against perm(inputs) = outputs.  The wire indices of
+ * PoseidonEntry / SwapOption::addr are circuit bookkeeping and are not produced. */
 #define RSV_TRANSCRIPT_WORDS 284
 typedef struct {
     uint32_t n_queries, max_log, n_inner; /* declared common shape; ignored when no path output is requested */
@@ -340,6 +401,11 @@ typedef struct {
     uint32_t* d_fri_cols;
     uint32_t* d_fri_folded;
     uint32_t* d_query_values;
+    /* PoseidonFlow (ABI v3), see below */
+    uint32_t* d_flow;
+    uint8_t* d_flow_swap;
+    uint32_t* d_flow_count;
+    uint32_t flow_stride;
 } rsv_hints_out;
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,
@@ -349,6 +415,8 @@ int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
 int rsv_verify_hints(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
                      const rsv_public_input* pi, size_t n_pi,
                      const rsv_hints_out* out, uint8_t* accept, uint8_t* reason, int device);
+/* Records in the PoseidonFlow of one proof with these component log sizes under cfg (pure arithmetic, no device). */
+int rsv_poseidon_flow_count(uint32_t log_size_plonk, uint32_t log_size_poseidon, const rsv_pcs_config* cfg, uint32_t* count);
 /* Host-buffer convenience for the transcript rows only (any mix of shapes): out is [n][RSV_TRANSCRIPT_WORDS]. */
 int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg, uint32_t* out,
                          int device);

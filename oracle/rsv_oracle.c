@@ -189,11 +189,23 @@ int rsvo_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n) {
 }
 
 /* a4: primitives/poseidon31/src/lib.rs:282-311 (state = left||right, or right||left on swap) */
+/* Optional recorder (rsvo_poseidon_flow): every invocation appends what PoseidonFlow holds for it
+ * (constraint_system/src/plonk_with_poseidon.rs:117-128, primitives/poseidon31/src/lib.rs:385-415): the two input
+ * halves AS GIVEN (the accelerator applies the swap), the two output halves, the swap bit. */
+typedef struct { uint32_t* rec; size_t cap, n; } flow_recorder;
+static __thread flow_recorder* g_flow;
 static void half_permute(const m31* left, const m31* right, int swap, m31* rate, m31* cap) {
     m31 s[16];
     memcpy(s, swap ? right : left, 32);
     memcpy(s + 8, swap ? left : right, 32);
     poseidon2(s);
+    if (g_flow) {
+        if (g_flow->n < g_flow->cap) {
+            uint32_t* r = g_flow->rec + 33 * g_flow->n;
+            memcpy(r, left, 32); memcpy(r + 8, right, 32); memcpy(r + 16, s, 64); r[32] = swap ? 1u : 0u;
+        }
+        g_flow->n++;
+    }
     if (rate) memcpy(rate, s, 32);
     if (cap) memcpy(cap, s + 8, 32);
 }
@@ -534,12 +546,19 @@ static void run_transcript(const proof_view* v, transcript* t) {
     memcpy(t->pow_digest, ch.digest, 32);
     t->pow_ok = (ch.digest[0] & ((1u << v->cfg.pow_bits) - 1)) == 0; /* fiat_shamir/src/lib.rs:115-117 */
     uint32_t nq = v->cfg.n_queries, got = 0; /* fiat_shamir/src/lib.rs:119-130 */
+    uint32_t draws = 0;
     while (got < nq) {
         qm31 a, b2;
         ch_draw(&ch, &a, &b2);
+        draws++;
         uint32_t w[8] = {a.a.a, a.a.b, a.b.a, a.b.b, b2.a.a, b2.a.b, b2.b.a, b2.b.b};
         for (int i = 0; i < 8 && got < nq; i++) t->raw_queries[got++] = w[i];
     }
+    /* The circuit draws ceil(n_q / 4) times and truncates (fiat_shamir/src/lib.rs:119-130: one draw = two felts = 8
+     * words, so ceil(n_q / 8) draws already hold every query): the surplus draws change no value, but each is a
+     * Poseidon invocation of the circuit — replayed only when the flow is being recorded. */
+    if (g_flow)
+        for (; draws < (nq + 3) / 4; draws++) { qm31 a, b2; ch_draw(&ch, &a, &b2); }
 }
 
 /* Test-vector helper (not part of the verify path): find a proof-of-work nonce >= start for the proof as it stands
@@ -1513,5 +1532,136 @@ int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi,
     }
 done:
     free(pr->pair_records); free(pr);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY 8f.1, second half: the VALUE side of the recursion circuit's Poseidon accelerator — PoseidonFlow
+ * (constraint_system/src/plonk_with_poseidon.rs:36,117-128): one record per Poseidon2HalfVar::permute invocation
+ * (primitives/poseidon31/src/lib.rs:282-423), in the order the circuit that verifies this proof makes them
+ * (examples/multi-proofs/src/main.rs:69-139):
+ *   FiatShamirResults::compute        every channel operation                  fiat_shamir/src/lib.rs:44-130
+ *   AnswerResults::compute            tree 0 for every query in TRANSCRIPT order, then trees 1, 2, 3;
+ *                                     one SinglePathMerkleProofVar::verify each   answer/src/lib.rs:214-258,
+ *                                                                                 data_structures/src/lib.rs:315-354
+ *   FoldingResults::compute           the first-layer SinglePairMerkleProofVar::verify of every query, then per inner
+ *                                     layer one per query                      folding/src/lib.rs:23-33,186-189,
+ *                                                                              data_structures/src/lib.rs:400-464
+ * (CompositionCheck and the quotient / fold arithmetic invoke no permutation.)  The restatement below runs exactly
+ * those per-path verifications — on the per-query paths rsvo_trace_paths / rsvo_trace_cols / rsvo_fri_paths extract,
+ * i.e. what SinglePathMerkleProof / SinglePairMerkleProof::from_stwo_proof hand the circuit — with the recorder of
+ * half_permute switched on, so the records come out in invocation order by construction.
+ * out: [count][33] = left8 | right8 | out_rate8 | out_cap8 | swap.  Returns RSV_OK and *count (also when cap is too
+ * small: then only the first cap records are written and the return value is RSV_E_CAP).
+ * Pinned by the reference only through the COUNT (tests/test_oracle.py: the padded flow of level K's verification is
+ * the Poseidon trace of level K+1, whose log size is written in that fixture's header); beyond that: parity unpinned. */
+static void flow_sponge_rate(const m31* cols, size_t n, m31* out) { /* hash_m31_columns_get_rate, merkle/src/lib.rs:50-91 */
+    static const m31 zero8[8] = {0};
+    m31 d[8];
+    sponge_capacity(cols, n, d);
+    half_permute(zero8, d, 0, out, NULL);
+}
+static void flow_qm31_capacity(const m31* v4, m31* d) { /* hash_qm31_columns_get_capacity(&[v, 0]), merkle/src/lib.rs:99-139 */
+    static const m31 zero8[8] = {0};
+    m31 chunk[8] = {v4[0], v4[1], v4[2], v4[3], 0, 0, 0, 0};
+    half_permute(chunk, zero8, 0, NULL, d);
+}
+static void flow_qm31_rate(const m31* v4, m31* out) { /* hash_qm31_columns_get_rate(&[v, 0]), merkle/src/lib.rs:93-97 */
+    static const m31 zero8[8] = {0};
+    m31 d[8];
+    flow_qm31_capacity(v4, d);
+    half_permute(zero8, d, 0, out, NULL);
+}
+
+int rsvo_poseidon_flow(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out,
+                       size_t cap, size_t* count) {
+    if (!proof || !count || (cap && !out)) return RSV_E_NULL;
+    int rc = RSV_OK;
+    proof_view* v = malloc(sizeof *v);
+    transcript* t = malloc(sizeof *t);
+    uint32_t *tsib = NULL, *tcols = NULL, *fsib = NULL, *fcols = NULL;
+    flow_recorder fr = {out, cap, 0};
+    if (!parse_proof(proof, len, NULL, v)) { rc = RSV_E_SIZE; goto done; }
+    const uint32_t nq = v->cfg.n_queries, M = v->M, A = v->A, B = v->B, nt = 1 + v->n_inner;
+    uint32_t tpos[4 * MAX_QUERIES], depth4[4], nq2 = 0, nt2 = 0;
+    tsib = malloc((size_t)4 * nq * M * 8 * 4); tcols = calloc((size_t)4 * MAX_QUERIES * 64, 4);
+    fsib = calloc((size_t)nt * nq * M * 8, 4); fcols = calloc((size_t)nt * nq * 3 * 8, 4);
+    /* the per-query paths (these calls verify the proof; a proof that does not verify has no flow) */
+    if (rsvo_trace_paths(proof, len, pi, n_pi, tsib, (size_t)4 * nq * M * 8, tpos, depth4, &nq2) != RSV_OK || nq2 != nq ||
+        rsvo_trace_cols(proof, len, pi, n_pi, tcols, (size_t)4 * MAX_QUERIES * 64, &nq2) != RSV_OK ||
+        rsvo_fri_paths(proof, len, pi, n_pi, fsib, (size_t)nt * nq * M * 8, fcols, &nt2, &nq2) != RSV_OK || nt2 != nt) {
+        rc = RSV_E_SIZE; goto done;
+    }
+    g_flow = &fr;
+    run_transcript(v, t);
+    /* AnswerResults::compute: four trees, every query in transcript order (answer/src/lib.rs:214-258) */
+    for (int tr = 0; tr < 4; tr++) {
+        static const uint32_t plonk_cols[3] = {10, 12, 8}, poseidon_cols[3] = {40, 48, 8};
+        uint32_t ncols_at[32] = {0};
+        if (tr < 3) { ncols_at[A] += plonk_cols[tr]; ncols_at[B] += poseidon_cols[tr]; } else ncols_at[M] = 8;
+        const uint32_t depth = depth4[tr];
+        for (uint32_t i = 0; i < nq; i++) {
+            /* SinglePathMerkleProofVar::verify (data_structures/src/lib.rs:315-354) */
+            const m31* cols = tcols + ((size_t)tr * nq + i) * 64;
+            const uint32_t query = tpos[tr * nq + i];
+            m31 cur[8];
+            flow_sponge_rate(cols, ncols_at[depth], cur);
+            cols += ncols_at[depth];
+            for (uint32_t k = 0; k < depth; k++) {
+                const uint32_t h = depth - k - 1;
+                const m31* sib = tsib + (((size_t)tr * nq + i) * M + k) * 8;
+                const int bit = (query >> k) & 1;
+                if (ncols_at[h]) { /* hash_tree_with_column_hash_with_swap (merkle/src/lib.rs:32-41): column hash first */
+                    m31 ch[8], tmp[8];
+                    sponge_capacity(cols, ncols_at[h], ch);
+                    cols += ncols_at[h];
+                    half_permute(cur, sib, bit, tmp, NULL);
+                    half_permute(tmp, ch, 0, cur, NULL);
+                } else half_permute(cur, sib, bit, cur, NULL); /* hash_tree_with_swap (merkle/src/lib.rs:22-30) */
+            }
+            if (memcmp(cur, v->commitments[tr], 32) != 0) rc = RSV_E_SIZE;
+        }
+    }
+    /* FoldingResults::compute: first layer for every query, then every inner layer for every query */
+    for (uint32_t s2 = 0; s2 < nt; s2++) {
+        const uint32_t depth = s2 == 0 ? M : M - s2;
+        uint8_t data[32] = {0};
+        if (s2 == 0) { data[M] = 1; data[A] = 1; data[B] = 1; } else data[depth] = 1;
+        const uint32_t* root = s2 == 0 ? v->first.commitment : v->inner[s2 - 1].commitment;
+        for (uint32_t i = 0; i < nq; i++) {
+            /* SinglePairMerkleProofVar::verify (data_structures/src/lib.rs:400-464) */
+            const uint32_t query = (t->raw_queries[i] & ((1u << M) - 1)) >> (M - depth);
+            const m31* cl = fcols + ((size_t)s2 * nq + i) * 3 * 8; /* c-th data level from the top: self | sibling */
+            const m31* sh = fsib + ((size_t)s2 * nq + i) * M * 8;
+            m31 self[8], sibling[8];
+            uint32_t c = 0;
+            flow_qm31_rate(cl, self);
+            flow_qm31_rate(cl + 4, sibling);
+            c++;
+            for (uint32_t k = 0; k < depth; k++) {
+                const uint32_t h = depth - k - 1;
+                const int bit = (query >> k) & 1;
+                if (!data[h] || h == 0) {
+                    half_permute(self, sibling, bit, self, NULL);
+                    if (k != depth - 1) memcpy(sibling, sh + 8 * k, 32);
+                } else {
+                    m31 sc[8], bc[8], tmp[8];
+                    flow_qm31_capacity(cl + 8 * c, sc);
+                    flow_qm31_capacity(cl + 8 * c + 4, bc);
+                    c++;
+                    half_permute(self, sibling, bit, tmp, NULL);
+                    half_permute(tmp, sc, 0, self, NULL);
+                    half_permute(sh + 8 * k, bc, 0, sibling, NULL);
+                }
+            }
+            if (memcmp(self, root, 32) != 0) rc = RSV_E_SIZE;
+        }
+    }
+    g_flow = NULL;
+    *count = fr.n;
+    if (rc == RSV_OK && fr.n > cap) rc = RSV_E_CAP;
+done:
+    g_flow = NULL;
+    free(tsib); free(tcols); free(fsib); free(fcols); free(t); free(v);
     return rc;
 }

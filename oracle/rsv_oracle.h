@@ -74,6 +74,12 @@ int rsvo_fri_folded(const uint8_t* proof, size_t len, const rsv_public_input* pi
 int rsvo_fri_paths(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* sib,
                    size_t cap, uint32_t* cols, uint32_t* n_trees, uint32_t* n_queries);
 
+/* SURVEY 8f.1, second half: PoseidonFlow of the circuit that verifies `proof` — one record of 33 words
+ * (left8 | right8 | out_rate8 | out_cap8 | swap) per Poseidon2HalfVar::permute invocation, in invocation order
+ * (layout and order: rsv_oracle.c).  *count receives the number of invocations (also when cap is too small). */
+int rsvo_poseidon_flow(const uint8_t* proof, size_t len, const rsv_public_input* pi, size_t n_pi, uint32_t* out,
+                       size_t cap, size_t* count);
+
 /* ---- rsv_emulated.c: the emulated Poseidon2 gadget over a minimal Plonk-without-Poseidon constraint system
  * (primitives/poseidon31/src/emulated.rs:80-221, constraint_system/src/plonk_without_poseidon.rs) */
 typedef struct rsvo_ecs rsvo_ecs;

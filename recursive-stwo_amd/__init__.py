@@ -118,7 +118,9 @@ class HintsOut(ctypes.Structure):  # rsv_hints_out
     _fields_ = [("n_queries", ctypes.c_uint32), ("max_log", ctypes.c_uint32), ("n_inner", ctypes.c_uint32),
                 ("d_transcript", ctypes.c_void_p), ("d_trace_sib", ctypes.c_void_p), ("d_trace_pos", ctypes.c_void_p),
                 ("d_trace_cols", ctypes.c_void_p), ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p),
-                ("d_fri_folded", ctypes.c_void_p), ("d_query_values", ctypes.c_void_p)]
+                ("d_fri_folded", ctypes.c_void_p), ("d_query_values", ctypes.c_void_p),
+                ("d_flow", ctypes.c_void_p), ("d_flow_swap", ctypes.c_void_p), ("d_flow_count", ctypes.c_void_p),
+                ("flow_stride", ctypes.c_uint32)]
 
 
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
@@ -145,6 +147,7 @@ def _load() -> ctypes.CDLL:
         "rsv_ctx_destroy": (None, [vp]),
         "rsv_ctx_synchronize": (ctypes.c_int, [vp]),
         "rsv_ctx_stream": (vp, [vp]),
+        "rsv_ctx_set_option": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_longlong]),
         "rsv_poseidon2_permute": (ctypes.c_int, [_u32p, _u32p, sz, ctypes.c_int]),
         "rsv_poseidon2_permute_dev": (ctypes.c_int, [vp, vp, vp, sz, vp]),
         "rsv_ctx_wait_stream": (ctypes.c_int, [vp, vp]),
@@ -173,6 +176,7 @@ def _load() -> ctypes.CDLL:
         "rsv_verify_hints": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.POINTER(HintsOut), _u8p, _u8p,
                                             ctypes.c_int]),
         "rsv_transcript_batch": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), _u32p, ctypes.c_int]),
+        "rsv_poseidon_flow_count": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(PcsConfig), _u32p]),
         "rsv_fri_paths_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
                                              ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp]),
         "rsv_fri_paths": (ctypes.c_int, [_u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32, ctypes.c_uint32,
@@ -191,13 +195,13 @@ def _load() -> ctypes.CDLL:
 
 lib = _load()
 EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_destroy", "rsv_ctx_synchronize",
-           "rsv_ctx_stream", "rsv_ctx_wait_stream", "rsv_stream_wait_ctx", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
+           "rsv_ctx_stream", "rsv_ctx_set_option", "rsv_ctx_wait_stream", "rsv_stream_wait_ctx", "rsv_poseidon2_permute", "rsv_poseidon2_permute_dev", "rsv_poseidon2_half_permute",
            "rsv_poseidon2_emulated", "rsv_poseidon2_emulated_dev",
            "rsv_merkle_hash_node", "rsv_merkle_path_root", "rsv_transcript", "rsv_verify_batch",
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
            "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
-           "rsv_transcript_batch"]
+           "rsv_transcript_batch", "rsv_poseidon_flow_count"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -214,6 +218,25 @@ def _u32(a, shape=None) -> np.ndarray:
 
 def device_count() -> int:
     return lib.rsv_device_count()
+
+
+#: rsv_option (include/rsv.h) by name, and the named values of the three-way knobs (0 is always "automatic")
+OPTIONS = {"transcript_form": 1, "transcript_split": 2, "oods_form": 3, "qconst_form": 4, "plan_form": 5, "tree_cap": 6,
+           "overlap_trees": 7, "ws_budget_mb": 8, "perm_wg_per_cu": 9, "host_chunk_mb": 10, "host_threads": 11, "debug_log": 12,
+           "critical_chain": 13}
+OPTION_VALUES = {"auto": 0, "row": 1, "lane": 2, "whole": 1, "split": 2, "parallel": 1, "serial": 2, "on": 1, "off": 2}
+
+
+def _set_option(handle, name: str, value) -> None:
+    v = OPTION_VALUES[value] if isinstance(value, str) else int(value)
+    _check(lib.rsv_ctx_set_option(handle, OPTIONS[name], v), f"rsv_ctx_set_option({name}={value})")
+
+
+def set_default_option(name: str, value) -> None:
+    """Process default of a tuning / diagnostic knob (rsv_ctx_set_option with ctx = NULL): inherited by every context
+    created afterwards, including the ones the host-pointer entry points create for themselves.  The library never reads
+    the environment."""
+    _set_option(None, name, value)
 
 
 def make_inputs(inputs: Iterable) -> "ctypes.Array[PublicInput]":
@@ -435,6 +458,32 @@ def transcript_batch(proofs: Sequence[bytes], cfg, device: int = 0) -> np.ndarra
     return out
 
 
+def poseidon_flow_count(log_size_plonk: int, log_size_poseidon: int, cfg) -> int:
+    """Records in the PoseidonFlow of one proof of this shape (rsv_poseidon_flow_count)."""
+    c = PcsConfig(cfg.pow_bits, cfg.log_blowup_factor, cfg.log_last_layer_degree_bound, cfg.n_queries)
+    out = ctypes.c_uint32(0)
+    _check(lib.rsv_poseidon_flow_count(log_size_plonk, log_size_poseidon, ctypes.byref(c), ctypes.byref(out)), "rsv_poseidon_flow_count")
+    return int(out.value)
+
+
+def poseidon_flow(proofs: Sequence[bytes], cfg, flow_stride: int, inputs=STANDARD_INPUTS, device: int = 0):
+    """SURVEY 8f.1 (second half): the PoseidonFlow of the circuit that verifies each proof, from the verifying pass
+    (rsv_verify_hints with d_flow).  Returns (flow uint32[n, flow_stride, 32], swap uint8[n, flow_stride],
+    count uint32[n], accept, reason); record = left8 | right8 | out_rate8 | out_cap8."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    flow = np.zeros((n, flow_stride, 32), np.uint32)
+    swap = np.zeros((n, flow_stride), np.uint8)
+    count = np.zeros(n, np.uint32)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    ho = HintsOut(0, 0, 0, None, None, None, None, None, None, None, None, flow.ctypes.data, swap.ctypes.data, count.ctypes.data, flow_stride)
+    _check(lib.rsv_verify_hints(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), pi, len(list(inputs)),
+                                ctypes.byref(ho), accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_verify_hints")
+    return flow, swap, count, accept, reason
+
+
 def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
     """per-query pair paths of the FRI trees.  Returns (sib uint32[n,1+n_inner,nq,max_log,8],
     cols uint32[n,1+n_inner,nq,3,8], accept, reason)."""
@@ -466,11 +515,13 @@ class Context:
         _check(lib.rsv_ctx_create(device, ctypes.byref(h)), "rsv_ctx_create")
         self._h = h
         self.device = device
+        self._live = []
 
     def close(self):
         if self._h:
-            lib.rsv_ctx_destroy(self._h)
+            lib.rsv_ctx_destroy(self._h)  # waits for the context's streams
             self._h = None
+            self._live = []
 
     def __del__(self):
         try:
@@ -480,6 +531,26 @@ class Context:
 
     def synchronize(self):
         _check(lib.rsv_ctx_synchronize(self._h), "rsv_ctx_synchronize")
+        self._live = []
+
+    def set_option(self, name: str, value) -> None:
+        """A tuning / diagnostic knob of this context (rsv_ctx_set_option; names in OPTIONS)."""
+        _set_option(self._h, name, value)
+
+    def _keep(self, pc, cfg):
+        """A per-proof configuration index uploaded INSIDE a call (cfg was a list, not a PreparedCfg the caller holds)
+        lives in a torch tensor that the call's first kernel reads later, on this context's stream.  Were it to die with
+        the call, torch's caching allocator could hand its memory to the next allocation on torch's stream, which is not
+        ordered behind the context's.  So the context holds it: until synchronize() / close(), or — when many calls are
+        queued without one — until torch's current stream has been made to wait for the context (release_to_torch), after
+        which a reuse of the block is ordered behind every kernel that read it.  (A PreparedCfg the caller made is the
+        caller's to keep alive until the work is ordered, like the blob.)"""
+        if pc is cfg:
+            return
+        self._live.append(pc)
+        if len(self._live) > 16:
+            self.release_to_torch()
+            self._live = self._live[-1:]  # the newest belongs to the call that is about to be enqueued
 
     @property
     def stream(self) -> int:
@@ -522,6 +593,7 @@ class Context:
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(cfg, n)
         self.acquire_from_torch()
+        self._keep(pc, cfg)
         _check(lib.rsv_verify_batch_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
                "rsv_verify_batch_dev")
@@ -531,6 +603,7 @@ class Context:
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(cfg, n)
         self.acquire_from_torch()
+        self._keep(pc, cfg)
         _check(lib.rsv_trace_paths_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                        n_queries, max_log, d_sib.data_ptr(), d_pos.data_ptr(), d_accept.data_ptr(),
                                        d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
@@ -552,15 +625,17 @@ class Context:
 
     def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,
-                     d_fri_cols=None, d_fri_folded=None, d_query_values=None):
+                     d_fri_cols=None, d_fri_folded=None, d_query_values=None, d_flow=None, d_flow_swap=None, d_flow_count=None):
         """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
         shape = (n_queries, max_log, n_inner), needed for the path outputs."""
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
-                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded), ptr(d_query_values))
+                      ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded), ptr(d_query_values),
+                      ptr(d_flow), ptr(d_flow_swap), ptr(d_flow_count), int(d_flow.shape[1]) if d_flow is not None else 0)
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(cfg, n)
         self.acquire_from_torch()
+        self._keep(pc, cfg)
         _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")
 

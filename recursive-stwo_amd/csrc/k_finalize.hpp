@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const ProofMeta* _
     if (p >= n) return;
     uint32_t r = metas[p].reason;
     if (r == R_OK) {
-        uint32_t f = ctxs[p].flags;
+        uint32_t f = ctxs[p].flags & F_REASON_MASK;
         r = f ? (uint32_t)(__ffs((int)f) - 1) : R_OK;
     }
     accept[p] = r == R_OK;

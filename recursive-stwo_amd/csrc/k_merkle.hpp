@@ -28,6 +28,7 @@ struct RowHashArgs {
     const ProofMeta* metas;
     uint32_t* rowh;        // [slot][4][2][G][8] (this bucket's part of the row-hash workspace)
     const uint32_t* ids;   // slot -> proof (nullptr: identity)
+    ProofCtx* ctxs;        // flags: a non-canonical queried value -> RSV_R_PARSE
 };
 
 __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
@@ -49,9 +50,21 @@ __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     const uint32_t* qv = w + m.qv_off[t];
     const uint32_t qv_n = m.qv_n[t];
     uint32_t* out = a.rowh + (((size_t)slot * 4 + t) * 2) * G * 8;
-    if ((r + 1) * nc_leaf <= qv_n) store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity(qv + r * nc_leaf, nc_leaf)));
+    uint32_t over = 0;  // a non-canonical queried value (this kernel is where queried_values are read: layout.hpp)
+    if ((r + 1) * nc_leaf <= qv_n)
+        store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity_chk(qv + r * nc_leaf, nc_leaf, over)));
     if (nc_lower && (r + 1) * nc_lower <= qv_n)
-        store_hash(out + ((size_t)G + r) * 8, sponge_capacity(qv + qv_n - (r + 1) * nc_lower, nc_lower));
+        store_hash(out + ((size_t)G + r) * 8, sponge_capacity_chk(qv + qv_n - (r + 1) * nc_lower, nc_lower, over));
+    {
+        // The words no row covers: empty for every list the Merkle stage accepts (its rows tile the list: nd_leaf <= nq
+        // leaf rows from the start, nd_lower <= nq lower rows from the end); a longer or ragged list is rejected there,
+        // but its words are field elements all the same and a non-canonical one outranks that rejection.
+        const uint32_t nq = m.nq;
+        const uint32_t r1 = umin(nq, qv_n / nc_leaf), r2 = nc_lower ? umin(nq, qv_n / nc_lower) : 0u;
+        const uint32_t lo = r1 * nc_leaf, hi = qv_n - r2 * nc_lower;
+        for (uint32_t i = lo + r; i < hi; i += nq) over |= qv[i] >= P;
+    }
+    if (over) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);
 }
 
 // ----------------------------------------------------------- k_trace_merkle
@@ -149,16 +162,18 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
                 else {
                     const uint32_t wi = base + rank;
                     Hash8 w8 = zero8();
-                    if (wi < d.hw_n) w8 = load_hash(d.hw + 8 * wi);
-                    else bad = true;
+                    if (wi < d.hw_n) {
+                        w8 = load_hash(d.hw + 8 * wi);
+                        if (hash_over(w8)) atomicOr(d.flags, 1u << R_PARSE);
+                    } else bad = true;
                     left = (pres & 1u) ? load_hash(kids) : w8;
                     right = (pres & 2u) ? load_hash(kids + 8) : w8;
                 }
                 Hash8 node = hash_tree(left, right);
                 if (l == 0) {
-                    if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, 1u << d.fail_bit);
+                    if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, (1u << d.fail_bit) | (bad ? F_RESCAN : 0u));
                 } else {
-                    if (bad) atomicOr(d.flags, 1u << d.fail_bit);
+                    if (bad) atomicOr(d.flags, (1u << d.fail_bit) | F_RESCAN);
                     store_hash(xch[bufi ^ 1][(g2 << l) + ppos], node);
                     atomicOr(&mask[bufi ^ 1][g2], 1ull << ppos);
                 }
@@ -171,8 +186,12 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
     }
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<MerkleArgs> f) {
+// FLOW (a second instantiation, launched only when rsv_hints_out::d_flow is given, always with Lc = 0): every lane also
+// writes the PoseidonFlow records of ITS path — leaf sponge, one swap-permute per level, the lower column level's
+// sponge and combine — at the index the circuit's invocation order gives them (layout.hpp).  The circuit hashes every
+// query's leaf and column rows itself, so in this mode the lane does too (k_row_hash hashes each distinct row once).
+template <int BLOCK, bool FLOW = false>
+__global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(3);
     RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];
@@ -194,6 +213,8 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
     bool bad = false;
     Hash8 cur = zero8();
     uint32_t qj = 0;
+    FlowSink fs{nullptr, nullptr};  // FLOW: this proof's records (rec == nullptr: none)
+    uint32_t fbase = 0;             // FLOW: index of this path's first record
     if (live) {
         w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
         ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
@@ -208,8 +229,16 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
         qj = a.ctxs[p].q[j];
         rows = a.rowh + (((size_t)slot_ * 4 + t) * 2) * G * 8;
         const uint32_t row = ent_rb(ent[mx * G + j]);
+        if (FLOW && a.ctxs[p].flow_on) {
+            fs = fa.sink(p);
+            fbase = flow_trace_base(t, m->nq, m->n_inner, m->last_n, A, B, M) + a.ctxs[p].qperm[j] * flow_trace_path_len(t, A, B, M);
+        }
         if ((row + 1) * nc_leaf > qv_n) bad = true;
         else {
+            if (FLOW && fs.rec) {  // hash_m31_columns_get_rate (merkle/src/lib.rs:50-91): the chunks, then the rate permutation
+                const Hash8 d = flow_sponge_capacity(fs, fbase, w + m->qv_off[t] + row * nc_leaf, nc_leaf);
+                cur = rate_of(flow_perm(fs, fbase + flow_chunks(nc_leaf), zero8(), d, false));
+            } else
             cur = load_hash(rows + (size_t)row * 8);
             if (a.path_cols) {
                 uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64;
@@ -254,8 +283,12 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
             if (exch && ent_sib(e) != 0xFFu) sib = load_hash(xch[buf][gbase + ent_sib(e)]);
             else {
                 uint32_t wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
-                if (wi < hw_n) sib = load_hash(hw + 8 * wi);
-                else { sib = zero8(); bad = true; }
+                if (wi < hw_n) {
+                    sib = load_hash(hw + 8 * wi);
+                    // hash witnesses are read here, so here they are checked for canonicity (layout.hpp); raised at
+                    // once (a branch that is almost never taken) rather than carried in a register across the walk
+                    if (hash_over(sib)) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);
+                } else { sib = zero8(); bad = true; }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
             if (a.path_sib) {
@@ -263,15 +296,28 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
                 store_hash(a.path_sib + ((((size_t)slot_ * 4 + t) * G + oi) * a.pl.maxM + (mx - lvl)) * 8, sib);
                 if (lvl == mx) a.path_pos[((size_t)slot_ * 4 + t) * G + oi] = qj >> (M - mx);
             }
-            cur = hash_tree_swap(cur, sib, odd);
             const uint32_t pl_ = lvl - 1;  // parent level
             uint32_t nc = (t == 3 || pl_ == mx) ? 0u : ((pl_ == A ? plonk_cols(t) : 0u) + (pl_ == B ? poseidon_cols(t) : 0u));
+            // FLOW: records of this step (the circuit's loop index is mx - lvl): [column sponge chunks] swap-permute
+            // [combine]; the steps above the lower column level sit behind that level's chunks + combine
+            uint32_t fidx = 0;
+            if (FLOW && fs.rec) {
+                const uint32_t lower = (t == 3 || A == B) ? 0u : umin(A, B);
+                const uint32_t extra = (lower && pl_ < lower) ? flow_chunks(lower == A ? plonk_cols(t) : poseidon_cols(t)) + 1u : 0u;
+                fidx = fbase + flow_chunks(nc_leaf) + 1u + (mx - lvl) + extra;
+                cur = rate_of(flow_perm(fs, fidx + (nc ? flow_chunks(nc) : 0u), cur, sib, odd));
+            } else
+            cur = hash_tree_swap(cur, sib, odd);
             if (nc) {
                 // lower-level rows were hashed counting from the end of queried_values
                 const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
                 const uint32_t off = nd_leaf * nc_leaf + row * nc;
                 if (off + nc > qv_n || nd_lower - 1 - row >= G) bad = true;
                 else {
+                    if (FLOW && fs.rec) {  // hash_tree_with_column_hash_with_swap (merkle/src/lib.rs:32-41)
+                        const Hash8 colcap = flow_sponge_capacity(fs, fidx, w + m->qv_off[t] + off, nc);
+                        cur = rate_of(flow_perm(fs, fidx + flow_chunks(nc) + 1u, cur, colcap, false));
+                    } else
                     cur = combine_with_column(cur, load_hash(rows + ((size_t)G + (nd_lower - 1 - row)) * 8));
                     if (a.path_cols) {
                         uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64 + nc_leaf;
@@ -290,7 +336,9 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
         uint32_t want_qv = nd_leaf * nc_leaf + (lower ? lvl_nd(h->lvl[lower]) * nc_lower : 0u);
         uint32_t want_hw = lvl_s(h->lvl[1]) - s_top;
         bool ok = !bad && want_qv == qv_n && want_hw == hw_n && (Lc || hash_eq(cur, load_hash(w + W_COMMIT0 + 8 * t)));
-        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (R_MERKLE_T0 + t));
+        // a witness list of the wrong length is not read completely: k_rescan reads the whole proof (layout.hpp)
+        const uint32_t fl = (ok ? 0u : 1u << (R_MERKLE_T0 + t)) | ((bad || want_hw != hw_n) ? F_RESCAN : 0u);
+        if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
     if (Lc) {
         uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
@@ -302,8 +350,13 @@ __global__ __launch_bounds__(BLOCK, RSV_TRACE_WAVES) void k_trace_merkle(Fused<M
 // SinglePairMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:400-464):
 // blockIdx.y = 0 is the FRI first-layer tree (one QM31 column at each distinct
 // column log size), blockIdx.y = 1 + i the i-th inner layer (one column at the leaves).
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<MerkleArgs> f) {
+// FLOW (second instantiation, Lc = 0, with the dynamic LDS buffer): every lane also writes the PoseidonFlow records of
+// its pair path (layout.hpp): the two leaf sponges, one swap-permute per level and, at a lower column level of the
+// first-layer tree, the two column capacities and the two combines — the sibling node's combine is then computed by
+// the lane itself from the sibling's children hash (another lane's, through xch2, or hashed from the witness pair,
+// which the circuit takes as a hint and does not hash).
+template <int BLOCK, bool FLOW = false>
+__global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(4);
     RSV_FUSED_SELECT(f, a, bx);
     __shared__ uint32_t xch[2][BLOCK][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
@@ -331,6 +384,8 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
     bool bad = false, have_sib = false;
     uint32_t* psib = nullptr;
     Hash8 cur = zero8(), sibh = zero8();
+    FlowSink fs{nullptr, nullptr};  // FLOW: this proof's records (rec == nullptr: none)
+    uint32_t fbase = 0;             // FLOW: index of this path's first record
     if (live) {
         w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
         ent = a.pl.ent + (size_t)slot_ * (a.pl.maxM + 1) * G;
@@ -344,8 +399,17 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
         s_top = lvl_s(h->lvl[top]);
         leafv = a.leafv + ((size_t)slot_ * (3 + a.maxInner)) * G * 8;
         const uint32_t* lv = leafv + ((size_t)(slot == 0 ? 0 : 2 + slot) * G + j) * 8;
+        if (FLOW && c->flow_on) {
+            fs = fa.sink(p);
+            fbase = flow_pair_base(slot, m->nq, m->n_inner, m->last_n, m->A, m->B, M) + c->qperm[j] * flow_pair_path_len(slot, m->A, m->B, M);
+        }
+        if (FLOW && fs.rec) {  // hash_qm31_columns_get_rate(&[v, 0]) of the query's own value, then of its pair sibling's
+            cur = rate_of(flow_perm(fs, fbase + 1u, zero8(), flow_capacity4(fs, fbase, lv), false));
+            sibh = rate_of(flow_perm(fs, fbase + 3u, zero8(), flow_capacity4(fs, fbase + 2u, lv + 4), false));
+        } else {
         cur = leaf_from_capacity(sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
         sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+        }
         have_sib = true;
         dslot = 0;
         if (a.pair_sib) {
@@ -389,6 +453,7 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
     for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
         const bool on = live && lvl <= top;
         const uint32_t pl_ = lvl - 1;
+        uint32_t fidx = 0;
         const bool exA = (needA >> lvl) & 1u, exB = (needB >> lvl) & 1u;  // workgroup-uniform
         // is the parent level a data level of the first-layer tree?
         int dg = -1;
@@ -408,20 +473,30 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
                     uint32_t wi;
                     if (slot == 0) wi = dg >= 0 ? (fl[dslot * G + j] & 0xFFFFu) : (uint32_t)h->wf[lvl] + ent_lb(e);
                     else wi = lvl_s(h->lvl[lvl + 1]) - s_top + ent_lb(e);
-                    if (wi < L->hash_n) sibh = load_hash(w + L->hash_off + 8 * wi);
-                    else { sibh = zero8(); bad = true; }
+                    if (wi < L->hash_n) {
+                        sibh = load_hash(w + L->hash_off + 8 * wi);
+                        if (hash_over(sibh)) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);  // as in k_trace_merkle
+                    } else { sibh = zero8(); bad = true; }
                 }
             }
             bool odd = (qj >> (M - lvl)) & 1u;
             // sibling_hashes[top-1-lvl]: the sibling at a level without a column (data levels: stored in phase B)
             if (psib && !have_sib) store_hash(psib + (size_t)(top - 1 - lvl) * 8, sibh);
+            // FLOW: the records of this step (circuit loop index top - lvl, behind four extra records per column level
+            // already passed): swap-permute alone, or [self column capacity, sibling column capacity, swap-permute,
+            // combine self, combine sibling] when the parent level carries a column
+            fidx = fbase + 4u + (top - lvl) + 4u * dslot;
+            if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + (dg >= 0 ? 2u : 0u), cur, sibh, odd));
+            else
             cur = hash_tree_swap(cur, sibh, odd);
             have_sib = false;
         }
         // phase B: data level of the first-layer tree: fold in the column and build the sibling node
         if (on && dg >= 0) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
-            if (a.pair_sib) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
+            if (a.pair_sib || FLOW) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
+            if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + 3u, cur, flow_capacity4(fs, fidx, lv), false));
+            else
             cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
             store_hash(xcol[threadIdx.x], cur);
         }
@@ -435,10 +510,16 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
                 if (ent_sib(e) != 0xFFu) {
                     sibh = load_hash(xcol[gbase + ent_sib(e)]);
                     if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, load_hash(xch2[gbase + ent_sib(e)]));
+                    if (FLOW && fs.rec)  // the circuit combines sibling_hashes[i] with the sibling's column itself
+                        sibh = rate_of(flow_perm(fs, fidx + 4u, load_hash(xch2[gbase + ent_sib(e)]), flow_capacity4(fs, fidx + 1u, lv + 4), false));
                 } else bad = true;
             } else if (w_sib + 1 < L->hash_n) {
-                Hash8 sn = hash_tree(load_hash(w + L->hash_off + 8 * w_sib), load_hash(w + L->hash_off + 8 * (w_sib + 1)));
+                const Hash8 wl = load_hash(w + L->hash_off + 8 * w_sib), wr = load_hash(w + L->hash_off + 8 * (w_sib + 1));
+                if (hash_over(wl) | hash_over(wr)) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);
+                Hash8 sn = hash_tree(wl, wr);
                 if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, sn);
+                if (FLOW && fs.rec) sibh = rate_of(flow_perm(fs, fidx + 4u, sn, flow_capacity4(fs, fidx + 1u, lv + 4), false));
+                else
                 sibh = combine_with_column(sn, sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
             } else bad = true;
             have_sib = true;
@@ -448,7 +529,8 @@ __global__ __launch_bounds__(BLOCK, RSV_PAIR_WAVES) void k_pair_merkle(Fused<Mer
     if (live) {
         uint32_t want_hw = slot == 0 ? (uint32_t)h->wf_total : lvl_s(h->lvl[1]) - s_top;
         bool ok = !bad && want_hw == L->hash_n && (Lc || hash_eq(cur, load_hash(w + L->commit_off)));
-        if (!ok) atomicOr(&a.ctxs[p].flags, 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER));
+        const uint32_t fl = (ok ? 0u : 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER)) | ((bad || want_hw != L->hash_n) ? F_RESCAN : 0u);
+        if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
     if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u);
 }

@@ -210,11 +210,15 @@ __device__ __noinline__ void oods_eval_row(const uint32_t* w, uint32_t lp, uint3
         if (k == lq - 1u) vq = cur;
         if (k == kb) vb = cur;
     }
+    // (a vanishing value of zero — an OODS point on one of the trace cosets, reachable only through the probe — has
+    // the inverse 0 the lane form's separate q_inv gives it, and must not zero the other component's inverse)
     QM31 dinv_p, dinv_q;
     {
-        QM31 ti = q_inv(q_mul(vp, vq));
-        dinv_p = q_mul(ti, vq);
-        dinv_q = q_mul(ti, vp);
+        const bool zp = q_eq(vp, q_zero()), zq = q_eq(vq, q_zero());
+        const QM31 fp = zp ? one : vp, fq = zq ? one : vq;
+        QM31 ti = q_inv(q_mul(fp, fq));
+        dinv_p = zp ? q_zero() : q_mul(ti, fq);
+        dinv_q = zq ? q_zero() : q_mul(ti, fp);
     }
     // ---- plonk component (6 constraints): sequential, identical on every lane
     EvalCtx e;

@@ -1,4 +1,4 @@
-// k_parse.hpp — wire-format walk (k_parse) and canonicity scan (k_scan).  Part of the pipeline described in verify.hpp.
+// k_parse.hpp — wire-format walk (k_parse) and the canonicity fallback scan (k_rescan).  Part of the pipeline described in verify.hpp.
 #pragma once
 #include "verify_common.hpp"
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     ProofMeta& m = metas[p];
-    ctxs[p].flags = 0;
+    ctxs[p].flags = 0;  // (front_over belongs to the front half of a split transcript, which may be running now)
     shape[2 * p] = 0;
     shape[2 * p + 1] = 0;
     uint64_t o0 = offsets[p], o1 = offsets[p + 1];
@@ -125,42 +125,51 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     atomicMax(&summary[7], ~sw2);
 }
 
-// ------------------------------------------------------------------- k_scan
-// Every field element of a proof must be a canonical M31 word (< P).  Exempt are the words that are not field
-// elements and that nothing else constrains: the two halves of the proof-of-work nonce, and the proof's final word,
-// last_layer_poly.log_size — the reference never reads it (it takes the size from coeffs.len(),
-// components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any u32 there verifies.  A wave reads
-// one proof at a time with 16-byte coalesced loads (grid-stride over the proofs: the launcher throttles the grid) —
-// this pass is the "proof bytes read once" leg of the HBM roofline.
-__global__ __launch_bounds__(256) void k_scan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                                              uint32_t n, ProofMeta* __restrict__ metas) {
-    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t wave = wave0; wave < n; wave += n_waves) {
-    ProofMeta& m = metas[wave];
-    if (m.reason != R_OK) continue;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[wave]);
-    const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
-    auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
-    uint32_t bad = 0;
-    // align the vector loop to 16 bytes
-    uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
-    head = umin(head, nw);
-    if (lane < head) bad |= (w[lane] >= P) && !exempt(lane);
-    const uint4* v = reinterpret_cast<const uint4*>(w + head);
-    uint32_t nv = (nw - head) >> 2;
-    for (uint32_t i = lane; i < nv; i += 64) {
-        uint4 x = v[i];
-        uint32_t base = head + 4 * i;
-        uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
-        if (o) {
-            for (int k = 0; k < 4; k++)
-                if (((o >> k) & 1) && !exempt(base + k)) bad = 1;
+// ----------------------------------------------------------------- k_rescan
+// Canonicity fallback (layout.hpp, F_RESCAN): a proof in which some stage found a witness list of the wrong length —
+// already rejected by that stage — is read once in full here, so that a non-canonical word in the part of the list
+// nobody consumed still gives RSV_R_PARSE, the reason include/rsv.h defines for it.  Every field element of a proof must be a
+// canonical M31 word (< P); exempt are the words that are not field elements and that nothing else constrains: the
+// two halves of the proof-of-work nonce, and the proof's final word, last_layer_poly.log_size — the reference never
+// reads it (it takes the size from coeffs.len(), components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any
+// u32 there verifies.  One lane looks at one proof's flag; the wave then reads the flagged proofs of its 64 one after
+// the other with 16-byte coalesced loads.  In a batch of well-formed and bit-flipped proofs nothing is flagged and the
+// kernel reads 8 bytes per proof (rounds 1-2 read every proof a second time: 7.7 GB per 65 536-proof step).
+// force: every parsed proof is read (the single-proof probe rsv_transcript, which runs no Merkle stage).
+__global__ __launch_bounds__(256) void k_rescan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                                uint32_t n, const ProofMeta* __restrict__ metas,
+                                                ProofCtx* __restrict__ ctxs, uint32_t force) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = mine < n && metas[mine].reason == R_OK && (force || (ctxs[mine].flags & F_RESCAN));
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const uint32_t src = (uint32_t)__ffsll((long long)todo) - 1u;
+        todo &= todo - 1ull;
+        const uint32_t p = mine - lane + src;
+        const ProofMeta& m = metas[p];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+        const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
+        auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
+        uint32_t bad = 0;
+        // align the vector loop to 16 bytes
+        uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
+        head = umin(head, nw);
+        if (lane < head) bad |= (w[lane] >= P) && !exempt(lane);
+        const uint4* v = reinterpret_cast<const uint4*>(w + head);
+        uint32_t nv = (nw - head) >> 2;
+        for (uint32_t i = lane; i < nv; i += 64) {
+            uint4 x = v[i];
+            uint32_t base = head + 4 * i;
+            uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
+            if (o) {
+                for (int k = 0; k < 4; k++)
+                    if (((o >> k) & 1) && !exempt(base + k)) bad = 1;
+            }
         }
-    }
-    uint32_t tail = head + 4 * nv;
-    if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
-    if (__any(bad) && lane == 0) m.reason = R_PARSE;
+        uint32_t tail = head + 4 * nv;
+        if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
+        if (__any(bad) && lane == 0) atomicOr(&ctxs[p].flags, 1u << R_PARSE);
     }
 }
 

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void k_plan(const uint8_t* __restrict__ blob, c
             c.fw_base[g] = base;
             base += (h.lvl[c.sizes[g]] >> 8) & 0xFFu;
         }
-        if (base != m.first.wit_n) flags |= 1u << R_FRI_FIRST;
+        if (base != m.first.wit_n) flags |= (1u << R_FRI_FIRST) | F_RESCAN;  // list not read completely: layout.hpp
     }
     // first-layer pair tree hash-witness plan (components/hints/src/folding.rs:107-206)
     {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ 
             c->fw_base[g] = base;
             base += (tl[grp][sizes[g]] >> 8) & 0xFFu;
         }
-        if (base != m->first.wit_n) flags |= 1u << R_FRI_FIRST;
+        if (base != m->first.wit_n) flags |= (1u << R_FRI_FIRST) | F_RESCAN;  // list not read completely: layout.hpp
     }
     __syncthreads();
     if (live) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_export_transcript(uint32_t n, const Pro
     const ProofMeta& m = metas[p];
     const ProofCtx& c = ctxs[p];
     uint32_t v = 0;
-    if (m.reason != R_OK) v = k == 0 ? (uint32_t)R_PARSE : 0u;
+    if (m.reason != R_OK || (c.flags & (1u << R_PARSE))) v = k == 0 ? (uint32_t)R_PARSE : 0u;
     else if (k == 0) v = (c.flags & (1u << R_POW)) ? (uint32_t)R_POW : (uint32_t)R_OK;
     else if (k == 1) v = m.n_inner + 1;
     else if (k == 2) v = m.nq;

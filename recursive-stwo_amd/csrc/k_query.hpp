@@ -179,6 +179,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
             else {
                 uint32_t wi = c->fw_base[g] + ent_lb(e);
                 sib = wi < m->first.wit_n ? ldq(w + m->first.wit_off + 4 * wi) : q_zero();
+                if ((sib.a.a >= P) | (sib.a.b >= P) | (sib.b.a >= P) | (sib.b.b >= P)) flags |= 1u << R_PARSE;  // fri_witness is read here (layout.hpp)
             }
             uint32_t* lv = leafv + ((size_t)g * G + j) * 8;
             stq(lv, answer); stq(lv + 4, sib);
@@ -219,8 +220,10 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
             else {
                 uint32_t wi = ent_lb(e);
                 sib = wi < L.wit_n ? ldq(w + L.wit_off + 4 * wi) : q_zero();
+                if ((sib.a.a >= P) | (sib.a.b >= P) | (sib.b.a >= P) | (sib.b.b >= P)) flags |= 1u << R_PARSE;
             }
-            if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= 1u << R_FRI_INNER;  // hints/src/folding.rs:558
+            // a witness list of the wrong length is not read completely: k_rescan reads the whole proof (layout.hpp)
+            if (j == 0 && lvl_tl(h->lvl[l]) != L.wit_n) flags |= (1u << R_FRI_INNER) | F_RESCAN;  // hints/src/folding.rs:558
             uint32_t* lv = leafv + ((size_t)(3 + i) * G + j) * 8;
             stq(lv, folded); stq(lv + 4, sib);
             if (qv) stq(qv + 24 + 4 * i, folded);

@@ -7,9 +7,13 @@ namespace rsv {
 // ------------------------------------------------------------- k_transcript
 // FiatShamirResults::compute (components/recursive/fiat_shamir/src/lib.rs:44-130):
 // a strictly sequential chain of channel permutations per proof.
+// FLOW: also writes the PoseidonFlow records of the channel operations (layout.hpp; rsv_hints_out::d_flow), including
+// the surplus query draws the circuit makes (it draws ceil(n_queries / 4) times where ceil(n_queries / 8) hold every
+// query, fiat_shamir/src/lib.rs:119-130), and decides whether this proof's records fit the caller's stride.
+template <bool FLOW>
 __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                    uint32_t n, const ProofMeta* __restrict__ metas,
-                                                   ProofCtx* __restrict__ ctxs) {
+                                                   ProofCtx* __restrict__ ctxs, FlowArgs fa) {
     RSV_TAG(1);
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -19,18 +23,32 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     Channel ch;
     ch.init();
+    if (FLOW) {
+        const uint32_t total = flow_total(m.nq, m.n_inner, m.last_n, m.A, m.B, m.M);
+        const bool fits = total <= fa.stride;
+        c.flow_on = fits ? 1u : 0u;
+        if (fa.count) fa.count[p] = fits ? total : 0u;
+        if (fits) ch.flow = fa.sink(p);
+    }
     Hash8 d;
-    ch.mix(load_hash(w + W_COMMIT0));
+    // Every field element the transcript absorbs is checked for canonicity here, where it is read (layout.hpp).
+    uint32_t over = 0;
+    auto ldq_chk = [&](const uint32_t* q) {
+        const QM31 v = ldq(q);
+        over |= (v.a.a >= P) | (v.a.b >= P) | (v.b.a >= P) | (v.b.b >= P);
+        return v;
+    };
+    ch.mix(load_hash_chk(w + W_COMMIT0, over));
     ch.mix_one(q_from_m(m.lp));  // statement 0: data_structures/src/lib.rs:52-55
     ch.mix_one(q_from_m(m.lq));
-    ch.mix(load_hash(w + W_COMMIT0 + 8));
+    ch.mix(load_hash_chk(w + W_COMMIT0 + 8, over));
     d = ch.draw();  // lookup elements z, alpha: data_structures/src/lib.rs:242-245
     stq(c.z, q_lo(d)); stq(c.alpha, q_hi(d));
-    ch.mix_two(ldq(w + W_PLONK_SUM), ldq(w + W_POSEIDON_SUM));  // statement 1: data_structures/src/lib.rs:85-87
-    ch.mix(load_hash(w + W_COMMIT0 + 16));
+    ch.mix_two(ldq_chk(w + W_PLONK_SUM), ldq_chk(w + W_POSEIDON_SUM));  // statement 1: data_structures/src/lib.rs:85-87
+    ch.mix(load_hash_chk(w + W_COMMIT0 + 16, over));
     d = ch.draw();
     stq(c.rc, q_lo(d));
-    ch.mix(load_hash(w + W_COMMIT0 + 24));
+    ch.mix(load_hash_chk(w + W_COMMIT0 + 24, over));
     d = ch.draw();
     QM31 t = q_lo(d);
     stq(c.oods_t, t);
@@ -42,23 +60,23 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
     }
 #pragma unroll 1
     for (int k = 0; k < N_SAMPLES; k += 2)  // fiat_shamir/src/lib.rs:68-75
-        ch.mix_two(ldq(w + SAMPLES.off[k]), ldq(w + SAMPLES.off[k + 1]));
+        ch.mix_two(ldq_chk(w + SAMPLES.off[k]), ldq_chk(w + SAMPLES.off[k + 1]));
     d = ch.draw();
     stq(c.after, q_lo(d));
-    ch.mix(load_hash(w + m.first.commit_off));
+    ch.mix(load_hash_chk(w + m.first.commit_off, over));
     d = ch.draw();
     stq(c.fri_alpha[0], q_lo(d));
 #pragma unroll 1
     for (uint32_t i = 0; i < m.n_inner; i++) {
-        ch.mix(load_hash(w + m.inner[i].commit_off));
+        ch.mix(load_hash_chk(w + m.inner[i].commit_off, over));
         d = ch.draw();
         stq(c.fri_alpha[i + 1], q_lo(d));
     }
 #pragma unroll 1
     for (uint32_t i = 0; i < m.last_n; i += 2) {  // fiat_shamir/src/lib.rs:94-100
         const uint32_t* cf = w + m.last_off + 4 * i;
-        if (i + 1 < m.last_n) ch.mix_two(ldq(cf), ldq(cf + 4));
-        else ch.mix_one(ldq(cf));
+        if (i + 1 < m.last_n) ch.mix_two(ldq_chk(cf), ldq_chk(cf + 4));
+        else ch.mix_one(ldq_chk(cf));
     }
     // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
     uint64_t nonce = (uint64_t)w[m.nonce_off] | ((uint64_t)w[m.nonce_off + 1] << 32);
@@ -73,7 +91,10 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
         d = ch.draw();
         for (int k = 0; k < 8 && got < m.nq; k++) c.raw_q[got++] = d.w[k];
     }
-    c.flags = flags;
+    if (FLOW)  // the circuit's surplus draws: same channel, no new value
+        for (uint32_t draws = (m.nq + 7u) / 8u; draws < (m.nq + 3u) / 4u; draws++) (void)ch.draw();
+    if (over) flags |= 1u << R_PARSE;
+    if (flags) atomicOr(&c.flags, flags);  // k_parse zeroed it; k_row_hash may be raising bits beside this kernel
 }
 
 // --------------------------------------------------------- k_transcript_row
@@ -123,9 +144,20 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     // Every word the chain absorbs is fetched BEFORE the permutation that precedes its use: a load issued between
     // two permutations is consumed at once and costs the row its whole HBM latency (1-2 us, against 2-3 us for the
     // permutation itself).
-    auto word_of = [&](const uint32_t* src, uint32_t n_words) { return (rate && i < n_words) ? src[i] : 0u; };
+    // Everything word_of / sample_word fetch is a field element the transcript absorbs: checked for canonicity here,
+    // where it is read (layout.hpp); the lanes' findings are added up over the row at the end.
+    uint32_t over = 0;
+    auto word_of = [&](const uint32_t* src, uint32_t n_words) {
+        const uint32_t v = (rate && i < n_words) ? src[i] : 0u;
+        over |= v >= P;
+        return v;
+    };
     auto store_felt = [&](uint32_t* dst, uint32_t out) { if (i < 4) dst[i] = out; };
-    auto sample_word = [&](int k) { return rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u; };
+    auto sample_word = [&](int k) {
+        const uint32_t v = rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u;
+        over |= v >= P;
+        return v;
+    };
     uint32_t nxt = 0, out;
     if (PHASE != 2) {
     const uint32_t c0 = word_of(w + W_COMMIT0, 8), c1 = word_of(w + W_COMMIT0 + 8, 8), c2 = word_of(w + W_COMMIT0 + 16, 8);
@@ -163,8 +195,10 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     }
     out = draw();
     store_felt(c.after, out);
-    if (PHASE == 1) {  // hand the digest to the back half
+    if (PHASE == 1) {  // hand the digest (and what the canonicity check found) to the back half
+        const uint32_t ov = sum_row(over);
         if (!rate) c.pow_digest[i - 8] = dg;
+        if (i == 0) c.front_over = ov;
         return;
     }
     }  // PHASE != 2
@@ -199,7 +233,12 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     mix(i == 0 ? (uint32_t)(nonce & ((1u << 22) - 1)) : i == 1 ? (uint32_t)((nonce >> 22) & ((1u << 21) - 1))
         : i == 2 ? (uint32_t)((nonce >> 43) & ((1u << 21) - 1)) : 0u);
     if (!rate) c.pow_digest[i - 8] = dg;
-    if (i == 8) c.flags = (dg & ((1u << m.pow_bits) - 1u)) ? (1u << R_POW) : 0u;  // fiat_shamir/src/lib.rs:115-117
+    {
+        uint32_t ov = sum_row(over);
+        if (PHASE == 2) ov += c.front_over;
+        const uint32_t fl = ((dg & ((1u << m.pow_bits) - 1u)) ? (1u << R_POW) : 0u) | (ov ? (1u << R_PARSE) : 0u);  // fiat_shamir/src/lib.rs:115-117
+        if (i == 8 && fl) atomicOr(&c.flags, fl);  // k_parse zeroed it; k_row_hash may be raising bits beside this kernel
+    }
 #pragma unroll 1
     for (uint32_t got = 0; got < m.nq; got += 8) {  // fiat_shamir/src/lib.rs:119-130
         out = draw();

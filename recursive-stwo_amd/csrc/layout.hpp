@@ -82,9 +82,23 @@ struct QBatch {
     uint32_t prx[2], pix[2], pry[2], piy[2];  // sample point: x = prx + pix*u, y = pry + piy*u (CM31 each)
 };
 
+// Canonicity (every field-element word of a proof must be < P, else RSV_R_PARSE) is checked WHERE THE WORDS ARE READ:
+// the transcript checks what it absorbs (total sums, commitments, sampled values, FRI commitments, last-layer
+// coefficients), k_row_hash the queried values, k_query the FRI witness values, the Merkle kernels the hash witnesses;
+// every other word is a length prefix or header word that k_parse pins to a small value.  A non-canonical word
+// raises bit RSV_R_PARSE of ProofCtx::flags (the lowest reason, so it outranks every later stage, as the dedicated
+// scan of rounds 1-2 did).  A witness list is read completely exactly when the stage that consumes it finds its
+// length right; a stage that finds it wrong (the proof is rejected there anyway) also raises F_RESCAN, and k_rescan
+// then reads that proof once in full, so that the REASON is the defined one (PARSE if any word anywhere is non-canonical).
+constexpr uint32_t F_RESCAN = 1u << 30;
+constexpr uint32_t F_REASON_MASK = (1u << 13) - 1u;
+
 // Written by k_transcript / k_plan, read by the per-query kernels.
 struct ProofCtx {
     uint32_t flags;
+    uint32_t flow_on;        // PoseidonFlow emission: 1 when this proof's records fit the caller's stride (k_transcript)
+    uint32_t front_over;     // split transcript: the front half saw a non-canonical word (it may not touch `flags`,
+                             // which the parser zeroes while the front half runs)
     uint32_t n_sizes;
     uint32_t sizes[3];       // distinct column log sizes, descending (M first)
     uint32_t fw_base[3];     // first-layer fri_witness base index per size
@@ -98,6 +112,50 @@ struct ProofCtx {
     uint32_t n_batches[3];
     uint32_t apow[N_APOW][4];  // -2u * after^k
 };
+
+// ---- PoseidonFlow (include/rsv.h: rsv_hints_out::d_flow) -------------------------------------------
+// One record per Poseidon2HalfVar::permute invocation of the circuit that verifies the proof, in the circuit's
+// invocation order (constraint_system/src/plonk_with_poseidon.rs:117-128; order: examples/multi-proofs/src/main.rs:69-139):
+//   [transcript][tree 0: one path per query, TRANSCRIPT query order][tree 1][tree 2][tree 3]
+//   [FRI first layer: one pair path per query][inner layer 0: one per query] ... [inner layer n_inner - 1]
+// The position of every record follows from the proof's shape alone, so each kernel writes the records of the
+// permutations it executes at their final index; nothing is appended.
+__host__ __device__ constexpr uint32_t flow_chunks(uint32_t n_cols) { return (n_cols + 7u) / 8u; }
+// FiatShamirResults::compute (components/recursive/fiat_shamir/src/lib.rs:44-130): 4 mixes + draw, mix + mix + draw,
+// mix + draw, 71 mixes + draw, (mix + draw) per FRI layer, the last-layer polynomial two felts per mix, the nonce,
+// ceil(n_queries / 4) draws (the circuit draws two felts per four queries and truncates).
+__host__ __device__ constexpr uint32_t flow_transcript_len(uint32_t nq, uint32_t n_inner, uint32_t last_n) {
+    return 82u + 2u * (1u + n_inner) + (last_n + 1u) / 2u + 1u + (nq + 3u) / 4u;
+}
+// SinglePathMerkleProofVar::verify (components/recursive/data_structures/src/lib.rs:315-354): leaf sponge + rate,
+// one swap-permute per level, and at the lower column level the column sponge and the combine.
+__host__ __device__ constexpr uint32_t flow_trace_path_len(int t, uint32_t A, uint32_t B, uint32_t M) {
+    const uint32_t mx = t == 3 ? M : (A > B ? A : B);
+    const uint32_t nc_leaf = t == 3 ? 8u : ((A == mx ? plonk_cols(t) : 0u) + (B == mx ? poseidon_cols(t) : 0u));
+    const uint32_t nc_lower = (t == 3 || A == B) ? 0u : (A < B ? plonk_cols(t) : poseidon_cols(t));
+    return flow_chunks(nc_leaf) + 1u + mx + (nc_lower ? flow_chunks(nc_lower) + 1u : 0u);
+}
+// SinglePairMerkleProofVar::verify (data_structures/src/lib.rs:400-464): 2 + 2 leaf permutations, one swap-permute per
+// level, and four more at every lower column level of the first-layer tree (two column capacities, two combines).
+__host__ __device__ constexpr uint32_t flow_pair_path_len(uint32_t s, uint32_t A, uint32_t B, uint32_t M) {
+    return s == 0 ? 4u + M + 4u * (A == B ? 1u : 2u) : 4u + (M - s);
+}
+__host__ __device__ constexpr uint32_t flow_trace_base(int t, uint32_t nq, uint32_t n_inner, uint32_t last_n, uint32_t A, uint32_t B,
+                                                       uint32_t M) {
+    uint32_t at = flow_transcript_len(nq, n_inner, last_n);
+    for (int k = 0; k < t; k++) at += nq * flow_trace_path_len(k, A, B, M);
+    return at;
+}
+__host__ __device__ constexpr uint32_t flow_pair_base(uint32_t s, uint32_t nq, uint32_t n_inner, uint32_t last_n, uint32_t A, uint32_t B,
+                                                      uint32_t M) {
+    uint32_t at = flow_trace_base(4, nq, n_inner, last_n, A, B, M);
+    for (uint32_t k = 0; k < s; k++) at += nq * flow_pair_path_len(k, A, B, M);
+    return at;
+}
+__host__ __device__ constexpr uint32_t flow_total(uint32_t nq, uint32_t n_inner, uint32_t last_n, uint32_t A, uint32_t B, uint32_t M) {
+    return flow_pair_base(1u + n_inner, nq, n_inner, last_n, A, B, M);
+}
+constexpr uint32_t FLOW_WORDS = 32;  // left8 | right8 | out_rate8 | out_cap8 (one 128-byte line); the swap bit is a byte of its own
 
 // Per-proof decommitment plan (k_plan), indexed by tree level l = 0..M and lane j
 // (lane j owns the j-th smallest query):

@@ -10,6 +10,14 @@
 
 namespace rsv {
 
+// 1 when some word of the hash is not a canonical M31 (layout.hpp: canonicity is checked where words are read)
+__device__ __forceinline__ uint32_t hash_over(const Hash8& h) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= h.w[i] >= P;
+    return o;
+}
+
 // hash_m31_columns_get_capacity (primitives/merkle/src/lib.rs:141-181):
 // d = 0; for each zero-padded chunk of 8 words: d = perm(chunk || d)[8..16].
 // `cols` may be any address space; words are read with plain 4-byte loads.
@@ -19,6 +27,18 @@ __device__ inline Hash8 sponge_capacity(const uint32_t* cols, uint32_t n) {
         Hash8 chunk;
 #pragma unroll
         for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
+        d = perm_cap(chunk, d);
+    }
+    return d;
+}
+// the same, reporting a non-canonical column word through `over`
+__device__ inline Hash8 sponge_capacity_chk(const uint32_t* cols, uint32_t n, uint32_t& over) {
+    Hash8 d = zero8();
+    for (uint32_t off = 0; off < n; off += 8) {
+        Hash8 chunk;
+#pragma unroll
+        for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
+        over |= hash_over(chunk);
         d = perm_cap(chunk, d);
     }
     return d;
@@ -56,12 +76,76 @@ __device__ inline Hash8 hash_node(const Hash8* l, const Hash8* r, const uint32_t
     return h;
 }
 
+// ---- PoseidonFlow records (layout.hpp; include/rsv.h: rsv_hints_out::d_flow) --------------------------------------
+// Where a proof's records go.  rec == nullptr: emission off.
+struct FlowSink {
+    uint4* rec;     // [stride][8] uint4 = 32 words per record, already offset to the proof
+    uint8_t* swap;  // [stride], already offset to the proof
+};
+// The caller's buffers (kernel argument)
+struct FlowArgs {
+    uint32_t* rec;     // [n][stride][32]   (nullptr: no flow)
+    uint8_t* swap;     // [n][stride]
+    uint32_t* count;   // [n] or nullptr: records of proof i (0: rejected by the parser, or the stride is too small)
+    uint32_t stride;
+    __device__ FlowSink sink(uint32_t p) const {
+        return FlowSink{reinterpret_cast<uint4*>(rec) + (size_t)p * stride * 8, swap + (size_t)p * stride};
+    }
+};
+// One invocation: the two input halves AS GIVEN (the accelerator applies the swap:
+// primitives/poseidon31/src/lib.rs:385-415), the output state, the swap bit.  One whole 128-byte line per record.
+__device__ __forceinline__ void flow_put(const FlowSink& f, uint32_t idx, const Hash8& l, const Hash8& r, const State16& out, uint32_t swap) {
+    uint4* q = f.rec + (size_t)idx * 8;
+    q[0] = make_uint4(l.w[0], l.w[1], l.w[2], l.w[3]);
+    q[1] = make_uint4(l.w[4], l.w[5], l.w[6], l.w[7]);
+    q[2] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+    q[3] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[4 + k] = make_uint4(out.s[4 * k], out.s[4 * k + 1], out.s[4 * k + 2], out.s[4 * k + 3]);
+    f.swap[idx] = (uint8_t)swap;
+}
+// permute(left, right, swap) with its record: returns the output state
+__device__ inline State16 flow_perm(const FlowSink& f, uint32_t idx, const Hash8& l, const Hash8& r, bool swap) {
+    State16 st;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        st.s[i] = swap ? r.w[i] : l.w[i];
+        st.s[8 + i] = swap ? l.w[i] : r.w[i];
+    }
+    st = poseidon2(st);
+    flow_put(f, idx, l, r, st, swap ? 1u : 0u);
+    return st;
+}
+// hash_m31_columns_get_capacity with records idx, idx + 1, ... (one per 8-word chunk)
+__device__ inline Hash8 flow_sponge_capacity(const FlowSink& f, uint32_t idx, const uint32_t* cols, uint32_t n) {
+    Hash8 d = zero8();
+    for (uint32_t off = 0; off < n; off += 8) {
+        Hash8 chunk;
+#pragma unroll
+        for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
+        d = cap_of(flow_perm(f, idx++, chunk, d, false));
+    }
+    return d;
+}
+// hash_qm31_columns_get_capacity(&[v, 0]): one record
+__device__ inline Hash8 flow_capacity4(const FlowSink& f, uint32_t idx, const uint32_t* v) {
+    Hash8 chunk = zero8();
+    chunk.w[0] = v[0]; chunk.w[1] = v[1]; chunk.w[2] = v[2]; chunk.w[3] = v[3];
+    return cap_of(flow_perm(f, idx, chunk, zero8(), false));
+}
+
 // ChannelVar (primitives/channel/src/lib.rs:24-58)
 struct Channel {
     Hash8 digest;
     uint32_t n_sent;
-    __device__ void init() { digest = zero8(); n_sent = 0; }
-    __device__ void mix(const Hash8& left) { digest = perm_cap(left, digest); n_sent = 0; }
+    FlowSink flow;      // PoseidonFlow records of the channel operations (rec == nullptr: off)
+    uint32_t flow_idx;
+    __device__ void init() { digest = zero8(); n_sent = 0; flow.rec = nullptr; flow.swap = nullptr; flow_idx = 0; }
+    __device__ void mix(const Hash8& left) {
+        if (flow.rec) digest = cap_of(flow_perm(flow, flow_idx++, left, digest, false));
+        else digest = perm_cap(left, digest);
+        n_sent = 0;
+    }
     __device__ void mix_two(QM31 f, QM31 g) {
         Hash8 l;
         l.w[0] = f.a.a; l.w[1] = f.a.b; l.w[2] = f.b.a; l.w[3] = f.b.b;
@@ -73,6 +157,7 @@ struct Channel {
     __device__ Hash8 draw() {
         Hash8 l = zero8();
         l.w[0] = n_sent++;
+        if (flow.rec) return rate_of(flow_perm(flow, flow_idx++, l, digest, false));
         return perm_rate(l, digest);
     }
 };
@@ -90,6 +175,11 @@ __device__ __forceinline__ Hash8 load_hash(const uint32_t* p) {
 #pragma unroll
         for (int i = 0; i < 8; i++) h.w[i] = p[i];
     }
+    return h;
+}
+__device__ __forceinline__ Hash8 load_hash_chk(const uint32_t* p, uint32_t& over) {
+    Hash8 h = load_hash(p);
+    over |= hash_over(h);
     return h;
 }
 __device__ __forceinline__ void store_hash(uint32_t* p, const Hash8& h) {

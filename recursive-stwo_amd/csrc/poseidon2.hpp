@@ -8,11 +8,11 @@
 //
 // MI355X mapping: ONE LANE PER PERMUTATION.  The 16-word state lives in 16
 // VGPRs of one lane, so a wave64 advances 64 independent permutations with no
-// cross-lane traffic; round constants are wave-uniform and are fetched with
-// scalar loads (s_load_dwordx16 from constant memory -> SGPR operands), the
-// partial-round diagonal is a 31-bit rotate.  The rounds are real loops
-// (not unrolled) so one instance of the permutation is ~14 KB of code and stays
-// resident in the instruction cache.
+// cross-lane traffic.  The fast path (poseidon2_inline, below) is straight-line
+// code: round constants are 32-bit literals of a fused add + canonicalise, the
+// linear layers accumulate unreduced in 64 bits, the partial-round diagonal is
+// a multiply-accumulate by a power of two.  One out-of-line instance
+// (poseidon2(), ~30 KB of code in 38 VGPRs) is shared by every call site.
 #pragma once
 #include "field.hpp"
 
@@ -41,9 +41,6 @@ struct State16 {
      0x155a0b97, 0x53d1c6aa, 0x2bd20347, 0x279b3d73, 0x4f5f3c70, 0x0245af6c, 0x238359d3, 0x49966a59}}
 __constant__ __attribute__((aligned(64))) uint32_t RC_FULL[8][16] = RSV_RC_FULL_INIT;
 constexpr uint32_t RC_FULL_K[8][16] = RSV_RC_FULL_INIT;  // the same values as compile-time constants (literal operands)
-
-// what the linear layer of the LAST first-half full round adds: only lane 0 gets a constant (the first partial one)
-__constant__ __attribute__((aligned(64))) uint32_t RC_FIRST_PARTIAL[16] = {0x7f7ec4bf};
 
 // 14 constants + 2 words of padding (block loads)
 #define RSV_RC_PARTIAL_INIT { \
@@ -183,11 +180,6 @@ __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b_uniform, uint64
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
     return d;
 }
-__device__ __forceinline__ uint64_t mad64u(uint32_t a_uniform, uint32_t b, uint64_t c) {  // a in an SGPR, b in a VGPR
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "s"(a_uniform), "v"(b), "v"(c));
-    return d;
-}
 __device__ __forceinline__ uint32_t dbl32(uint32_t x) {  // x + x as a fast-class add (not a shift)
     uint32_t d;
     asm("v_add_u32 %0, %1, %1" RSV_PACE_DBL : "=v"(d) : "v"(x));
@@ -233,10 +225,9 @@ __device__ __forceinline__ void mds4_2x(uint32_t k2, uint32_t k4, uint32_t x0, u
     y3 = T4;
 }
 
-// V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i]   (+ 2*rc[i] for i < n_rc), inputs any u32 (< 2^32):
-// the matrix rows sum to at most 16 * 5 = 80, so every V[i] < 2 * 80 * 2^32 + 2^33 < 2^41.
-__device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, uint32_t v2, const uint32_t* s, uint64_t* V,
-                                         const uint32_t* rc, int n_rc) {
+// V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i], inputs any u32 (< 2^32): the matrix rows sum to at most 16 * 5 = 80, so
+// every V[i] < 2 * 80 * 2^32 < 2^40.  V never carries a round constant (they are literals of the fused reductions).
+__device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, const uint32_t* s, uint64_t* V) {
 #pragma unroll
     for (int g = 0; g < 4; g++)
         mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
@@ -244,103 +235,10 @@ __device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, uint32_t v2, 
     for (int j = 0; j < 4; j++) {
         uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            V[4 * g + j] = add64(V[4 * g + j], sum);
-            if (4 * g + j < n_rc) V[4 * g + j] = mad64u(rc[4 * g + j], v2, V[4 * g + j]);
-        }
+        for (int g = 0; g < 4; g++) V[4 * g + j] = add64(V[4 * g + j], sum);
     }
 }
 
-// 16 wave-uniform constants as ONE block (s_load_dwordx16 into SGPRs).  Per-constant scalar loads are consumed a few
-// instructions after their issue and stall the wave for the whole scalar-cache latency each time.
-__device__ __forceinline__ void load_rc16(const uint32_t* p, uint32_t* dst) {
-    const uint4* p4 = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-    for (int q = 0; q < 4; q++) { uint4 t4 = p4[q]; dst[4 * q] = t4.x; dst[4 * q + 1] = t4.y; dst[4 * q + 2] = t4.z; dst[4 * q + 3] = t4.w; }
-}
-
-#ifdef RSV_P2_OLD
-__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
-    uint64_t V[16];
-    const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
-    uint32_t v2;  // the constant 2 in a VGPR (multiplier of the SGPR-resident round constants)
-    asm volatile("v_mov_b32 %0, 2" : "=v"(v2));
-    // s: canonical input.  After every full-round linear layer: s[i] = canon(fold2(V[i])) in C.
-    {
-        uint32_t rc0[16];
-        load_rc16(RC_FULL[0], rc0);
-        mds16_2x(k2, k4, v2, s, V, rc0, 16);
-    }
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
-        // the next round's constants, issued ahead of the S-box layer that hides the load
-        uint32_t rcn[16];
-        load_rc16(r < 3 ? RC_FULL[r + 1] : RC_FIRST_PARTIAL, rcn);
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));       // fold <= P + 161 <= 2P
-        mds16_2x(k2, k4, v2, s, V, rcn, 16);  // r == 3: RC_FIRST_PARTIAL, zero for lanes 1..15 (keeps the loop uniform)
-    }
-    // partial rounds: lanes 1..15 stay lazily folded (< 2^31 + 2^18), lane 0 goes through the S-box
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
-    // 2 * diag: 2^(i+2) for lanes 1..15, as opaque wave-uniform multipliers
-    uint32_t kd[16];
-    kd[0] = k6;
-#define RSV_KD(i) kd[i] = opaque(4u << (i));
-    RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
-    RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
-#undef RSV_KD
-    // Unrolled, with the 14 partial-round constants loaded as one block: rcp[r + 1] is then an SGPR operand; a scalar
-    // load per round would be consumed ~7 instructions after its issue and stall the wave for its whole latency,
-    // 13 times per permutation.  rc4: the constants of the full round after the partial ones ride on the last partial
-    // round's accumulators; loaded one round ahead.
-    uint32_t rcp[16], rc4[16];
-    load_rc16(RC_PARTIAL, rcp);
-#pragma unroll
-    for (int r = 0; r < 14; r++) {
-        if (r == 12) load_rc16(RC_FULL[4], rc4);
-        const uint32_t rc_next = rcp[r < 13 ? r + 1 : 13];
-        uint32_t u0 = pow5(canon(s[0]));                                     // s[0] <= 2P
-        // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
-        uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
-#pragma unroll
-        for (int i = 2; i < 16; i += 2) { a = mad64(s[i], k2, a); b = mad64(s[i + 1], k2, b); }
-        uint64_t sum2 = add64(a, b);
-        // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50
-        uint64_t v0 = mad64(u0, k6, sum2);
-        if (r < 13) {
-            s[0] = fold2(mad64u(rc_next, v2, v0));
-#pragma unroll
-            for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
-        } else {
-            // the constants of the next full round ride on the accumulators
-            s[0] = fold2(mad64u(rc4[0], v2, v0));
-#pragma unroll
-            for (int i = 1; i < 16; i++) s[i] = fold2(mad64u(rc4[i], v2, mad64(s[i], kd[i], sum2)));
-        }
-    }
-#pragma unroll 1
-    for (int r = 4; r < 8; r++) {
-        uint32_t rcn[16];
-        load_rc16(RC_FULL[r < 7 ? r + 1 : 7], rcn);
-        if (r == 4) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) s[i] = pow5(canon(s[i]));           // s[i] < 2^31 + 2^19 <= 2P
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i++) s[i] = pow5(canon(fold2(V[i])));
-        }
-        if (r < 7) mds16_2x(k2, k4, v2, s, V, rcn, 16);
-        else mds16_2x(k2, k4, v2, s, V, nullptr, 0);
-    }
-    // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        uint32_t t = fold2(V[i]);
-        s[i] = min(t, t - P);
-    }
-}
-#else
 // Round constant + canonicalisation in one step.  t = fold2(V) with V the doubled accumulator of a linear layer
 // WITHOUT its round constant: t <= P + HI where HI bounds the accumulator's high word (160 after a full-round
 // layer, < 2^19 after a partial-round one).  With c = P - rc (a compile-time literal):
@@ -390,11 +288,11 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     uint64_t V[16];
     const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
     // s: canonical input.  V never carries a round constant: the constants are literals of the fused reductions.
-    mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<0, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<1, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<2, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<3, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    mds16_2x(k2, k4, s, V);
+    sbox_full<0, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<1, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<2, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<3, 0>(V, s); mds16_2x(k2, k4, s, V);
     // partial rounds: every lane lazily folded (<= P + 2^18), lane 0 goes through the S-box
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
@@ -410,10 +308,10 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     partial_round<6>(s, k2, k6, kd);  partial_round<7>(s, k2, k6, kd);  partial_round<8>(s, k2, k6, kd);
     partial_round<9>(s, k2, k6, kd);  partial_round<10>(s, k2, k6, kd); partial_round<11>(s, k2, k6, kd);
     partial_round<12>(s, k2, k6, kd); partial_round<13>(s, k2, k6, kd);
-    sbox_full4<0>(s);      mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<5, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<6, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
-    sbox_full<7, 0>(V, s); mds16_2x(k2, k4, 0u, s, V, nullptr, 0);
+    sbox_full4<0>(s);      mds16_2x(k2, k4, s, V);
+    sbox_full<5, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<6, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<7, 0>(V, s); mds16_2x(k2, k4, s, V);
     // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -421,7 +319,6 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
         s[i] = min(t, t - P);
     }
 }
-#endif
 
 #ifdef RSV_COUNT_PERMS
 // Diagnostic build only (make count): executed permutations per kernel tag — [2t] active lanes, [2t+1] wave-level calls.

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -26,11 +27,31 @@
 
 using namespace rsv;
 
+// Options (include/rsv.h: rsv_option).  Nothing in this library reads the environment: a knob is set through
+// rsv_ctx_set_option, on one context or (ctx == NULL) as the process default that contexts created later inherit.
+struct Options {
+    int transcript_form = 0;   // 0 auto (by batch size), 1 row, 2 lane
+    int transcript_split = 0;  // 0 auto, 1 one launch, 2 front + back
+    int oods_form = 0, qconst_form = 0;  // 0 auto, 1 row, 2 lane
+    int plan_form = 0;         // 0 / 1 one lane per (proof, query), 2 one lane per proof (the original)
+    int tree_cap = 0;          // 0 / 1 dense top-of-tree cap, 2 every path walks to the root
+    int overlap_trees = 0;     // 0 / 1 FRI trees beside the trace trees, 2 behind them
+    long long ws_budget_mb = 8192;
+    int perm_wg_per_cu = 8;
+    long long host_chunk_mb = 256;
+    int host_threads = 0;      // 0 = min(cores, 8)
+    int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
+};
+static Options g_default_options;
+static std::mutex g_options_mu;
+static std::atomic<int> g_debug_log{0};
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
-            if (getenv("RSV_DEBUG")) fprintf(stderr, "rsv: %s -> %s\n", #expr, hipGetErrorString(e_)); \
+            if (g_debug_log.load(std::memory_order_relaxed))                                       \
+                fprintf(stderr, "rsv: %s -> %s\n", #expr, hipGetErrorString(e_));                  \
             return RSV_E_DEVICE;                                                                   \
         }                                                                                          \
     } while (0)
@@ -60,6 +81,7 @@ struct rsv_ctx {
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
     HostPipe* host_pipe = nullptr;
+    Options opt;
 };
 
 namespace {
@@ -79,16 +101,20 @@ int select_device(int device) {
     return RSV_OK;
 }
 
+Options default_options() {
+    std::lock_guard<std::mutex> lk(g_options_mu);
+    return g_default_options;
+}
+
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 // k_permute is persistent: enough 256-thread workgroups to fill every SIMD of the device at the kernel's occupancy
-// (RSV_PERM_WG_PER_CU workgroups per CU; default 8 = twice what is resident, which evens out the tail: measured
+// (RSV_OPT_PERM_WG_PER_CU workgroups per CU; default 8 = twice what is resident, which evens out the tail: measured
 // 7.7 / 8.3 / 8.6 / 8.8 / 8.3 G permutations/s at 2 / 4 / 6 / 8 / 16), never more than one lane per state
-inline unsigned permute_grid(size_t n) {
+inline unsigned permute_grid(size_t n, int wg_per_cu) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    unsigned per_cu = 8;
-    if (const char* e = getenv("RSV_PERM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = (unsigned)v; }
+    const unsigned per_cu = (unsigned)wg_per_cu;
     const size_t want = (size_t)cus * per_cu;
     const size_t need = (n + 255) / 256;
     return (unsigned)(need < want ? need : want);
@@ -114,6 +140,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     rsv_ctx* c = new (std::nothrow) rsv_ctx();
     if (!c) return RSV_E_DEVICE;
     c->device = device;
+    c->opt = default_options();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
@@ -164,11 +191,47 @@ void rsv_ctx_destroy(rsv_ctx* c) {
 
 int rsv_ctx_synchronize(rsv_ctx* c) {
     if (!c) return RSV_E_NULL;
+    // every verify call joins its side streams into the main one before it returns — except on an error exit taken
+    // after the fork: wait for all three, so that a caller who synchronises after an error may free its buffers
+    HIP_TRY(hipStreamSynchronize(c->side));
+    HIP_TRY(hipStreamSynchronize(c->aux));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSV_OK;
 }
 
 void* rsv_ctx_stream(rsv_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
+    auto tri = [&](int* dst) { if (value < 0 || value > 2) return (int)RSV_E_RANGE; *dst = (int)value; return (int)RSV_OK; };
+    std::lock_guard<std::mutex> lk(g_options_mu);
+    Options& o = c ? c->opt : g_default_options;
+    switch (option) {
+        case RSV_OPT_TRANSCRIPT_FORM: return tri(&o.transcript_form);
+        case RSV_OPT_TRANSCRIPT_SPLIT: return tri(&o.transcript_split);
+        case RSV_OPT_OODS_FORM: return tri(&o.oods_form);
+        case RSV_OPT_QCONST_FORM: return tri(&o.qconst_form);
+        case RSV_OPT_PLAN_FORM: return tri(&o.plan_form);
+        case RSV_OPT_TREE_CAP: return tri(&o.tree_cap);
+        case RSV_OPT_OVERLAP_TREES: return tri(&o.overlap_trees);
+        case RSV_OPT_CRITICAL_CHAIN: return tri(&o.critical_chain);
+        case RSV_OPT_WS_BUDGET_MB:
+            if (value < 1 || value > (1ll << 20)) return RSV_E_RANGE;
+            o.ws_budget_mb = value; return RSV_OK;
+        case RSV_OPT_PERM_WG_PER_CU:
+            if (value < 1 || value > 8) return RSV_E_RANGE;
+            o.perm_wg_per_cu = (int)value; return RSV_OK;
+        case RSV_OPT_HOST_CHUNK_MB:
+            if (value < 1 || value > 16384) return RSV_E_RANGE;
+            o.host_chunk_mb = value; return RSV_OK;
+        case RSV_OPT_HOST_THREADS:
+            if (value < 0 || value > 64) return RSV_E_RANGE;
+            o.host_threads = (int)value; return RSV_OK;
+        case RSV_OPT_DEBUG_LOG:
+            if (value < 0 || value > 1) return RSV_E_RANGE;
+            g_debug_log.store((int)value); return RSV_OK;
+        default: return RSV_E_SIZE;
+    }
+}
 
 // Ordering against the caller's own streams.  Every entry point forks its side stream off the main one (ev_fork), so
 // ordering the main stream is enough.
@@ -194,7 +257,7 @@ int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out,
     if (n > ((size_t)1 << 31)) return RSV_E_SIZE;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return RSV_E_SIZE;
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n, c->opt.perm_wg_per_cu)), dim3(256), 0, c->stream,
                        reinterpret_cast<const uint4*>(d_in), reinterpret_cast<uint4*>(d_out), n, d_bad);
     HIP_TRY(hipGetLastError());
     return RSV_OK;
@@ -212,7 +275,7 @@ int rsv_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n, int d
     HIP_TRY(dbad.alloc(4));
     HIP_TRY(hipMemset(dbad.p, 0, 4));
     HIP_TRY(hipMemcpy(din.p, in16, 64 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n)), dim3(256), 0, 0, din.as<const uint4>(),
+    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n, default_options().perm_wg_per_cu)), dim3(256), 0, 0, din.as<const uint4>(),
                        dout.as<uint4>(), n, dbad.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     uint32_t bad = 0;

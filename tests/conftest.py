@@ -63,3 +63,29 @@ def rsv():
     """The product binding (loads csrc/librsv_hip.so; raises if it is not built)."""
     import rsvload
     return rsvload.load_package()
+
+
+class _Knobs:
+    """Process-default tuning knobs of the product library (rsv_ctx_set_option with ctx = NULL), restored to
+    "automatic" when the test ends.  The library never reads the environment."""
+
+    DEFAULTS = {"ws_budget_mb": 8192, "perm_wg_per_cu": 8, "host_chunk_mb": 256}
+
+    def __init__(self, rsv):
+        self.rsv, self.touched = rsv, set()
+
+    def set(self, name, value):
+        self.touched.add(name)
+        self.rsv.set_default_option(name, value)
+
+    def reset(self):
+        for name in self.touched:
+            self.rsv.set_default_option(name, self.DEFAULTS.get(name, 0))
+        self.touched.clear()
+
+
+@pytest.fixture
+def knobs(rsv):
+    k = _Knobs(rsv)
+    yield k
+    k.reset()

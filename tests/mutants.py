@@ -6,7 +6,7 @@ from tests import oracle_binding as ob
 
 
 def mutants_of(proof: bytes, rng, n_random: int):
-    batch = [b for _, b in ob.structural_mutants(proof)]
+    batch = [b for _, b in ob.structural_mutants(proof)] + [b for _, b in ob.noncanonical_structural_mutants(proof)]
     for pos, n, _ in ob.proof_layout(proof)["prefixes"]:
         for val in {max(n - 1, 0), n + 1, 0, 0xFFFFFFFF, (1 << 32) + n, 8 * n + 3} - {n}:
             b = bytearray(proof)

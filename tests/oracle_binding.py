@@ -287,6 +287,42 @@ def trace_paths(proof: bytes, n_queries: int, max_log: int, inputs=STANDARD_INPU
     return sib, pos, depth
 
 
+def poseidon_flow(proof: bytes, inputs=STANDARD_INPUTS):
+    """PoseidonFlow of the circuit that verifies `proof` (rsvo_poseidon_flow): uint32[count, 33] =
+    left8 | right8 | out_rate8 | out_cap8 | swap per Poseidon2HalfVar::permute invocation, in invocation order."""
+    b = np.frombuffer(proof, dtype=np.uint8)
+    pi = make_inputs(inputs)
+    lib.rsvo_poseidon_flow.restype = ctypes.c_int
+    lib.rsvo_poseidon_flow.argtypes = [_u8p, sz, ctypes.POINTER(PublicInput), sz, _u32p, sz, ctypes.POINTER(sz)]
+    count = sz(0)
+    rc = lib.rsvo_poseidon_flow(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), None, 0, ctypes.byref(count))
+    if rc not in (0, -4):
+        raise RuntimeError(f"rsvo_poseidon_flow -> {rc}")
+    out = np.zeros((count.value, 33), np.uint32)
+    rc = lib.rsvo_poseidon_flow(b.ctypes.data_as(_u8p), len(proof), pi, len(list(inputs)), out.ctypes.data_as(_u32p), count.value,
+                                ctypes.byref(count))
+    if rc != 0:
+        raise RuntimeError(f"rsvo_poseidon_flow -> {rc}")
+    return out
+
+
+ROWS_PER_INVOCATION = 6
+
+
+def flow_log_size(n_invocations: int) -> int:
+    """log2 of the Poseidon trace a flow of n invocations becomes: padded to a multiple of 16, at least 2 * N_LANES = 32
+    (PlonkWithPoseidonConstraintSystem::pad, constraint_system/src/plonk_with_poseidon.rs:282-300), SIX trace rows per
+    invocation, next power of two.  Six rows = the shape of the Poseidon AIR the verifier evaluates
+    (components/recursive/composition/src/poseidon.rs:73-241): one `is_first` row (the initial external matrix), two
+    `is_full` rows of two full rounds each, one partial row (all 14 partial rounds), two more full rows.  The count is
+    also forced by the fixtures: 6 is the only integer for which every one of the 15 consecutive fixture pairs of the
+    reference (tests/test_oracle.py::test_poseidon_flow_count_predicts_next_level) lands on the header's log size —
+    level2-1's flow needs <= 6.23 rows per invocation, level7-1's > 5.82.  (SURVEY §0 guessed 8 from small_proof.bin
+    alone, whose 32-invocation minimum fits 2^8 rows for 5..8.)"""
+    padded = max(32, -(-n_invocations // 16) * 16)
+    return (ROWS_PER_INVOCATION * padded - 1).bit_length()
+
+
 def trace_cols(proof: bytes, inputs=STANDARD_INPUTS):
     """-> uint32[4, nq, 64]: SinglePathMerkleProof::columns per query, leaf-level columns then lower-level ones."""
     b = np.frombuffer(proof, dtype=np.uint8)
@@ -505,6 +541,47 @@ def structural_mutants(proof: bytes):
     d = copy.deepcopy(base); d["last"].append(zero4); emit("last+1", d)
     d = copy.deepcopy(base); d["last"] = d["last"] + d["last"]; emit("last doubled", d)
     d = copy.deepcopy(base); d["last"] = []; emit("last empty", d)
+    return out
+
+
+def noncanonical_structural_mutants(proof: bytes):
+    """Proofs that are wrong twice: a witness list of the wrong length (the stage that consumes it rejects the proof and
+    never reads all of it) AND a non-canonical word in the part nobody consumes, or in an element that moved.  The
+    verdict is reject either way; the REASON must be PARSE (a non-canonical field element outranks every later
+    stage), which the product can only say if its canonicity check reaches words no stage reads (csrc/layout.hpp:
+    F_RESCAN).  Returns [(tag, bytes)]."""
+    import copy
+    base = split_variable_part(proof)
+    out = []
+    P_, MAXW = 0x7FFFFFFF, 0xFFFFFFFF
+
+    def emit(tag, d):
+        out.append((tag, join_variable_part(d)))
+
+    def bad8(k, val):
+        h = np.zeros(8, np.uint32); h[k] = val
+        return h
+
+    for t in range(4):
+        d = copy.deepcopy(base); d["hash_witness"][t].append(bad8(7, P_)); emit(f"hw[{t}]+P", d)
+        d = copy.deepcopy(base); d["hash_witness"][t] += [bad8(0, 5), bad8(3, MAXW), bad8(1, 6)]; emit(f"hw[{t}]+3 (middle one bad)", d)
+        if len(base["hash_witness"][t]) > 3:
+            d = copy.deepcopy(base); d["hash_witness"][t].pop(0); d["hash_witness"][t][-1] = bad8(2, P_); emit(f"hw[{t}]-1, last bad", d)
+        d = copy.deepcopy(base); d["queried_values"][t].append(np.uint32(P_)); emit(f"qv[{t}]+P", d)
+        qv = list(base["queried_values"][t])
+        d = copy.deepcopy(base); d["queried_values"][t] = qv + qv + qv; d["queried_values"][t][len(qv) + len(qv) // 2] = np.uint32(MAXW)
+        emit(f"qv[{t}] tripled, middle bad", d)
+        d = copy.deepcopy(base); d["queried_values"][t] = qv[: len(qv) // 2 + 3]; d["queried_values"][t][-2] = np.uint32(P_)
+        emit(f"qv[{t}] halved ragged, bad near the cut", d)
+    for i in range(len(base["layers"])):
+        d = copy.deepcopy(base); d["layers"][i]["fri_witness"].append(np.array([1, 2, P_, 4], np.uint32)); emit(f"layer[{i}].fri_witness+P", d)
+        d = copy.deepcopy(base); d["layers"][i]["hash_witness"].append(bad8(4, MAXW)); emit(f"layer[{i}].hash_witness+bad", d)
+        if len(base["layers"][i]["hash_witness"]) > 2:
+            d = copy.deepcopy(base); d["layers"][i]["hash_witness"].pop(0); d["layers"][i]["hash_witness"][-1] = bad8(6, P_)
+            emit(f"layer[{i}].hash_witness-1, last bad", d)
+        if len(base["layers"][i]["fri_witness"]) > 1:
+            d = copy.deepcopy(base); d["layers"][i]["fri_witness"].pop(0); d["layers"][i]["fri_witness"][-1] = np.array([P_, 0, 0, 0], np.uint32)
+            emit(f"layer[{i}].fri_witness-1, last bad", d)
     return out
 
 

@@ -31,8 +31,8 @@ def main():
         want = ob.perm_count(proof)
         counter()
         for env in ("1", "0"):
-            os.environ["RSV_CAP"] = env
-            os.environ["RSV_TRANSCRIPT"] = "lane"
+            rsv.set_default_option("tree_cap", "on" if env == "1" else "off")
+            rsv.set_default_option("transcript_form", "lane")
             acc, _ = rsv.verify_batch([proof] * n, ob.header_cfg(proof))  # genuine fixture: header == manifest configuration
             assert acc.all()
             per = counter()
@@ -47,7 +47,7 @@ def mixed():
     mixes = {"standard": ["recursive_proof_16_15.bin", "level3-1.bin", "level6-1.bin", "level7-1.bin"],
              "chain": ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
                        "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]}
-    os.environ["RSV_CAP"] = "1"
+    rsv.set_default_option("tree_cap", "on")
     for label, names in mixes.items():
         proofs = [open(os.path.join(ROOT, "tests", "golden", "proofs", f), "rb").read() for f in names]
         want = sum(ob.perm_count(p) for p in proofs) / len(proofs)

@@ -6,8 +6,9 @@ transcript-absorbed sections (commitments, sampled values, FRI layer commitments
 stopped by the proof of work: they reach the logup / composition checks, and — with query positions that no longer
 match the decommitments — the plan, Merkle and FRI kernels.
 single K: additionally verify the first K proofs of the shuffled corpus ONE PER CALL (uniform-batch path, natural slot
-order, the small-batch kernel forms) and in groups of 3 under the smallest workspace budget the library accepts (64 MB).  The
-kernel-form overrides RSV_TRANSCRIPT / RSV_OODS / RSV_QCONST / RSV_PLAN of the environment apply to every call."""
+order, the small-batch kernel forms) and in groups of 3 under the smallest workspace budget the library accepts (1 MB).  The
+kernel forms can be forced for every call with trailing name=value arguments (names of rsv.OPTIONS, e.g.
+transcript_form=lane oods_form=row plan_form=serial): they become process defaults (rsv_ctx_set_option, ctx = NULL)."""
 import json
 import os
 import sys
@@ -26,6 +27,10 @@ rsv = rsvload.load_package()
 
 
 def main():
+    for a in [a for a in sys.argv[1:] if "=" in a]:  # kernel-form overrides
+        name, value = a.split("=", 1)
+        rsv.set_default_option(name, value if value in rsv.OPTION_VALUES else int(value))
+        sys.argv.remove(a)
     n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["proofs"]
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
@@ -69,12 +74,12 @@ def main():
         for i in range(k):
             a, r = rsv.verify_batch([batch[i]], [cfgs[i]])
             one += int(a[0] != oacc[i] or r[0] != oreason[i])
-        os.environ["RSV_WS_BUDGET_MB"] = "1"
+        rsv.set_default_option("ws_budget_mb", 1)
         three = 0
         for i in range(0, k - 2, 3):
             a, r = rsv.verify_batch(batch[i:i + 3], cfgs[i:i + 3])
             three += int((a != oacc[i:i + 3]).any() or (r != oreason[i:i + 3]).any())
-        del os.environ["RSV_WS_BUDGET_MB"]
+        rsv.set_default_option("ws_budget_mb", 8192)
         print(f"single: {k} one-proof calls, mismatches {one}; {k // 3} three-proof calls under the minimum workspace budget, mismatches {three}")
         bad += one + three
     sys.exit(1 if bad else 0)

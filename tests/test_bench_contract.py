@@ -53,6 +53,9 @@ def test_bench_single_gpu_line():
     d = _check_line(out.stdout, 1)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert 4000 < d["cpu_baseline"]["perms_per_proof"] < 6000
+    assert d["cpu_baseline"]["one_thread"]["value"] > 0 and d["cpu_baseline"]["one_thread"]["cores"] == 1 and d["cpu_baseline"]["cpu_model"]
+    assert d["host_path"]["value"] > 0 and d["host_path"]["GBps"] > 0  # PCIe-inclusive rate, reported beside `value`
+    assert d["config"]["exchange"]["world_size"] == 1 and len(d["config"]["exchange"]["devices"]) == 1
     v = d["valu"]
     assert 0 < v["frac_of_ceiling"] <= 1.0 and 0 < v["pipeline_frac_of_ceiling"] <= 1.0
     assert v["ceiling_perms_per_s"] > v["poseidon2_perms_per_s"] > 1e9

@@ -406,6 +406,40 @@ def test_blob_produced_by_torch_kernels_right_before_verify(rsv):
     ctx.close()
 
 
+def test_per_proof_cfg_index_outlives_the_python_call(rsv):
+    """Context.verify_batch(cfg=[one PcsConfig per proof]) uploads the per-proof configuration index
+    into a torch tensor that only the call's local PreparedCfg owns, and the parser reads it later, on the context's
+    own stream.  Without a host synchronisation the tensor dies when the call returns; torch's caching allocator may
+    then hand the block to the very next allocation on torch's stream, which is not ordered behind the context's.  The
+    binding marks the tensor as in use by the context's stream (record_stream) and holds the last few.  Here: a long
+    queue of torch work in front of the verifier (so that the parser runs late), the call, and immediately afterwards
+    same-sized allocations filled with 0xFF (an index beyond the table: RSV_R_PARSE for every proof if it were read)."""
+    import torch
+    dev = torch.device("cuda:0")
+    names = ["recursive_proof_16_15.bin", "level8-1.bin", "level12-1.bin", "level2-1.bin"]
+    n = 2048
+    batch = [read_proof(names[i % 4]) for i in range(n)]
+    cfgs = [fixture_cfg(names[i % 4]) for i in range(n)]
+    blob, offsets = rsv.pack(batch)
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    junk = torch.zeros(64 << 20, dtype=torch.int32, device=dev)
+    ctx = rsv.Context(0)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for k in range(40):
+            junk += k  # ~20 GB of traffic on torch's stream: the verifier's first kernel starts milliseconds later
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=cfgs)  # per-proof list, uploaded inside the call
+        grabbed = [torch.full((n,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(8)]  # would reuse a freed block
+        ctx.synchronize()
+        assert d_acc.cpu().numpy().tolist() == [1] * n, rep
+        assert d_reason.cpu().numpy().tolist() == [0] * n, rep
+        del grabbed
+    ctx.close()
+
+
 def _corrupt(proof: bytes, rng, region_end: int, n_bytes: int) -> bytes:
     b = bytearray(proof)
     for _ in range(n_bytes):
@@ -443,7 +477,7 @@ def test_fuzzed_headers_and_prefixes_match_oracle(rsv):
     assert acc[-1] == 1
 
 
-def test_chunked_workspace_matches_unchunked(rsv, monkeypatch):
+def test_chunked_workspace_matches_unchunked(rsv):
     """A small workspace budget forces the per-query stages to run in several chunks."""
     import torch
     proof = read_proof("small_proof.bin")
@@ -454,9 +488,9 @@ def test_chunked_workspace_matches_unchunked(rsv, monkeypatch):
     d_blob = torch.from_numpy(blob.copy()).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     results = []
-    for budget in ("64", "8192"):
-        monkeypatch.setenv("RSV_WS_BUDGET_MB", budget)
+    for budget in (64, 8192):
         ctx = rsv.Context(0)
+        ctx.set_option("ws_budget_mb", budget)
         d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
         ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=fixture_cfg("small_proof.bin"), inputs=[(1, (1, 0, 0, 0))])
@@ -468,14 +502,14 @@ def test_chunked_workspace_matches_unchunked(rsv, monkeypatch):
     assert results[0][0] == want
 
 
-def test_cap_disabled_matches_cap_enabled(rsv, monkeypatch):
-    """RSV_CAP=0 walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
+def test_cap_disabled_matches_cap_enabled(rsv, knobs):
+    """tree_cap = off walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
     proof = read_proof("recursive_proof_16_15.bin")
     batch = [ob.tamper(proof, i) for i in range(48)] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
     cfgs = [fixture_cfg("recursive_proof_16_15.bin")] * 49 + [fixture_cfg("level1-5.bin"), fixture_cfg("level12-1.bin")]
-    monkeypatch.setenv("RSV_CAP", "0")
+    knobs.set("tree_cap", "off")
     a0, r0 = rsv.verify_batch(batch, cfgs)
-    monkeypatch.setenv("RSV_CAP", "1")
+    knobs.set("tree_cap", "on")
     a1, r1 = rsv.verify_batch(batch, cfgs)
     assert a0.tolist() == a1.tolist() and r0.tolist() == r1.tolist()
     assert a1[-3:].tolist() == [1, 1, 1]
@@ -504,9 +538,9 @@ def test_trace_paths_match_oracle(rsv, manifest, name):
 
 
 @pytest.mark.parametrize("mode", ["row", "lane"])
-def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+def test_transcript_kernels_row_and_lane(rsv, manifest, knobs, mode):
     """Both transcript kernels (one proof per 16-lane DPP row / one proof per lane) against the oracle."""
-    monkeypatch.setenv("RSV_TRANSCRIPT", mode)
+    knobs.set("transcript_form", mode)
     for entry in manifest:
         proof = read_proof(entry["file"])
         assert rsv.transcript(proof) == rsv._parse_transcript(ob.transcript_raw(proof)), (mode, entry["file"])
@@ -518,36 +552,48 @@ def test_transcript_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
 
 
-@pytest.mark.parametrize("blocks", ["1", "3", "0"])
-def test_throttled_canonicity_scan(rsv, monkeypatch, blocks):
-    """The canonicity scan walks the proofs with a throttled grid on large batches (a few workgroups, grid-stride over
-    the proofs).  Forced here on a small batch — one workgroup for 150 proofs, three, and the unthrottled launch —
-    with non-canonical words at the start, in the middle and at the end of every section and in the exempt words."""
-    monkeypatch.setenv("RSV_SCAN_BLOCKS", blocks)
+def test_canonicity_is_checked_where_words_are_read(rsv):
+    """Every field-element word of a proof must be < P, else RSV_R_PARSE.  Rounds 1-2 read every proof a second time
+    for this (a scan kernel); now each stage checks the words it reads anyway and only proofs whose witness lists have
+    the wrong length are re-read (csrc/layout.hpp).  Non-canonical words at the start, in the middle and at the end of
+    every section and in the exempt words (nonce halves, final word); then proofs that are wrong twice — a list of the
+    wrong length AND a non-canonical word where no stage reads — whose reason must still be PARSE, as the oracle says."""
     proof = read_proof("recursive_proof_16_15.bin")
     cfg = fixture_cfg("recursive_proof_16_15.bin")
     words = np.frombuffer(proof, np.uint32)
     lay = ob.proof_layout(proof)
-    spots = sorted({17, 60, len(words) - 2, len(words) - 1, lay["nonce_word"], lay["nonce_word"] + 1, lay["nonce_word"] - 1,
-                    lay["nonce_word"] + 2} | {pos + 2 for pos, n, _ in lay["prefixes"] if n and pos + 2 < len(words)})
+    spots = sorted({2, 9, 17, 48, 60, 894, len(words) - 2, len(words) - 1, lay["nonce_word"], lay["nonce_word"] + 1, lay["nonce_word"] - 1,
+                    lay["nonce_word"] + 2} | {pos + 2 for pos, n, _ in lay["prefixes"] if n and pos + 2 < len(words)}
+                   | {pos + 2 + k for pos, n, what in lay["prefixes"] if n > 4 and "inner_layers" not in what and what != "decommitments"
+                      and what != "queried_values" for k in (n // 2, n - 1)})
     batch = [proof]
-    for k in range(149):
+    for k in range(3 * len(spots)):
         w = words.copy()
-        w[spots[k % len(spots)]] = 0x7FFFFFFF + (k % 3)
+        w[spots[k % len(spots)]] = [0x7FFFFFFF, 0x80000000, 0xFFFFFFFF][k // len(spots)]
         batch.append(w.tobytes())
-    acc, reason = rsv.verify_batch(batch, cfg)
-    oacc, oreason = ob.verify_batch(batch, cfg)
+    n_spot = len(batch)
+    cfgs = [cfg] * n_spot
+    for name in ("recursive_proof_16_15.bin", "level2-1.bin", "level12-1.bin"):
+        mut = [b for _, b in ob.noncanonical_structural_mutants(read_proof(name))]
+        batch += mut
+        cfgs += [fixture_cfg(name)] * len(mut)
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
-    assert acc[0] == 1 and 1 in reason.tolist()
+    assert acc[0] == 1 and set(oreason[n_spot:].tolist()) == {1}
+    # the same mutants one proof per call (another grid, another workgroup geometry)
+    for b, c_, oa, orr in list(zip(batch, cfgs, oacc, oreason))[n_spot::7]:
+        a1, r1 = rsv.verify_batch([b], c_)
+        assert (int(a1[0]), int(r1[0])) == (int(oa), int(orr))
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_row_transcript_in_one_piece_and_split(rsv, monkeypatch, split):
+@pytest.mark.parametrize("split", ["whole", "split"])
+def test_row_transcript_in_one_piece_and_split(rsv, knobs, split):
     """The row-form transcript as one launch and as front (next to the parser, before any section offset is known) +
     back: the same verdicts, reasons and transcript rows, also for buffers the front half has to leave alone
     (empty, truncated inside the fixed-offset part, cut right behind it, misaligned length)."""
-    monkeypatch.setenv("RSV_TRANSCRIPT", "row")
-    monkeypatch.setenv("RSV_TRANSCRIPT_SPLIT", split)
+    knobs.set("transcript_form", "row")
+    knobs.set("transcript_split", split)
     proof = read_proof("recursive_proof_16_15.bin")
     cfg = fixture_cfg("recursive_proof_16_15.bin")
     batch = [proof, ob.tamper(proof, 3), b"", proof[:64], proof[:3576], proof[:3584], proof[:3620], proof[:len(proof) - 4],
@@ -715,11 +761,10 @@ def test_verify_hints_one_pass(rsv, manifest):
     ctx.close()
 
 
-@pytest.mark.parametrize("chunk_mb", ["1", "256"])
-def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
+@pytest.mark.parametrize("chunk_mb", [1, 256])
+def test_verify_batch_host_pipeline(rsv, manifest, chunk_mb):
     """rsv_verify_batch_host: one host buffer per proof, gather -> upload -> verify pipelined over chunks.  A 1 MB
     chunk size forces dozens of chunks through the three-slot ring; verdicts == oracle's, in input order."""
-    monkeypatch.setenv("RSV_HOST_CHUNK_MB", chunk_mb)
     proofs, cfgs = [], []
     for e in manifest:
         pr = read_proof(e["file"])
@@ -729,6 +774,7 @@ def test_verify_batch_host_pipeline(rsv, manifest, monkeypatch, chunk_mb):
     proofs += [read_proof("hybrid_hash.bin"), b"\x00" * 64, b""]
     cfgs += [fixture_cfg("hybrid_hash.bin"), cfgs[0], cfgs[0]]
     ctx = rsv.Context(0)
+    ctx.set_option("host_chunk_mb", chunk_mb)
     acc, reason = ctx.verify_batch_host(proofs, cfgs)
     oacc, oreason = ob.verify_batch(proofs, cfgs)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
@@ -841,9 +887,9 @@ def test_line_eval_matches_oracle(rsv, log_n):
     assert np.array_equal(rsv.line_eval(coeffs, xs), ob.line_eval(coeffs, xs))
 
 
-def test_plan_kernels_serial_and_parallel(rsv, manifest, monkeypatch):
+def test_plan_kernels_serial_and_parallel(rsv, manifest, knobs):
     """The decommitment plan has two implementations — one lane per (proof, query) with bitmask popcounts (default)
-    and the one-lane-per-proof walk it replaced (RSV_PLAN=serial).  Both must give the oracle's verdicts on the
+    and the one-lane-per-proof walk it replaced (plan_form = serial).  Both must give the oracle's verdicts on the
     whole fixture set plus structural mutants (whose rejection reasons depend on the plan's witness counts)."""
     std = [e for e in manifest if entry_inputs(e) == list(rsv.STANDARD_INPUTS)]
     proofs = [read_proof(e["file"]) for e in std]
@@ -854,7 +900,7 @@ def test_plan_kernels_serial_and_parallel(rsv, manifest, monkeypatch):
         cfgs += [fixture_cfg(e["file"])] * len(mut)
     oacc, oreason = ob.verify_batch(batch, cfgs)
     for mode in ("serial", "parallel"):
-        monkeypatch.setenv("RSV_PLAN", mode)
+        knobs.set("plan_form", mode)
         acc, reason = rsv.verify_batch(batch, cfgs)
         assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), mode
 
@@ -870,7 +916,7 @@ def test_reject_fixtures_behind_the_proof_of_work(rsv):
     assert reason.tolist() == oreason.tolist() == [4, 0, 5] * 3
 
 
-def test_big_shape_reject_fixtures_behind_the_proof_of_work(rsv, monkeypatch):
+def test_big_shape_reject_fixtures_behind_the_proof_of_work(rsv, knobs):
     """RSV_R_COMPOSITION on a 2^16 / 2^15 proof and RSV_R_DUP_QUERY on the 80-query shape (re-ground fixtures), in
     one mixed batch with genuine proofs around them, under both OODS kernels and both plan kernels."""
     names = ["recursive_proof_16_15_composition.bin", "recursive_proof_16_15.bin", "level1-5_dup_query.bin", "level1-5.bin",
@@ -881,17 +927,17 @@ def test_big_shape_reject_fixtures_behind_the_proof_of_work(rsv, monkeypatch):
     assert oacc.tolist() == [0, 1, 0, 1, 0, 1] and oreason.tolist() == [4, 0, 5, 0, 4, 0]
     for oods in ("row", "lane"):
         for plan in ("serial", "parallel"):
-            monkeypatch.setenv("RSV_OODS", oods)
-            monkeypatch.setenv("RSV_PLAN", plan)
+            knobs.set("oods_form", oods)
+            knobs.set("plan_form", plan)
             acc, reason = rsv.verify_batch(batch, cfgs)
             assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist(), (oods, plan)
 
 
 @pytest.mark.parametrize("mode", ["row", "lane"])
-def test_oods_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+def test_oods_kernels_row_and_lane(rsv, manifest, knobs, mode):
     """Both OODS kernels (one proof per 16-lane DPP row / one proof per lane): the probe on random samples and the
     whole pipeline on fixtures, wrong public inputs (logup) and the composition reject fixtures."""
-    monkeypatch.setenv("RSV_OODS", mode)
+    knobs.set("oods_form", mode)
     rng = np.random.default_rng(55)
     n = 200
     sm = rng.integers(0, P, (n, 142, 4), dtype=np.uint32)
@@ -1125,9 +1171,9 @@ def test_mixed_batch_split_into_several_launch_groups(rsv, monkeypatch):
     dev = torch.device("cuda:0")
     d_blob = torch.from_numpy(blob.copy()).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
-    for budget in ("64", "8192"):
-        monkeypatch.setenv("RSV_WS_BUDGET_MB", budget)
+    for budget in (64, 8192):
         ctx = rsv.Context(0)
+        ctx.set_option("ws_budget_mb", budget)
         d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
         ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=ctx.prepare_cfg(cfgs, n))
@@ -1138,13 +1184,13 @@ def test_mixed_batch_split_into_several_launch_groups(rsv, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["row", "lane"])
-def test_qconst_kernels_row_and_lane(rsv, manifest, monkeypatch, mode):
+def test_qconst_kernels_row_and_lane(rsv, manifest, knobs, mode):
     """Both forms of the query-independent quotient constants (one proof per 16-lane row / per lane): every fixture of
     the standard inputs accepts, tampers keep the oracle's reasons, and the per-query quotient / fold values — which
     consume every alpha power and every summed line coefficient — equal the oracle's for three size-group layouts
     (A > B, A == B, A < B)."""
     import torch
-    monkeypatch.setenv("RSV_QCONST", mode)
+    knobs.set("qconst_form", mode)
     std = [e for e in manifest if len(e["inputs"]) == 3 and e["expect"] == "ok"]
     batch = [read_proof(e["file"]) for e in std]
     cfgs = [fixture_cfg(e["file"]) for e in std]

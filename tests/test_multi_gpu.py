@@ -83,7 +83,11 @@ def test_bench_launches_its_own_ranks():
     d = _bench(["--gpus", "2", "--proofs", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"],
                {"RSV_BENCH_REHEARSAL": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "shard2"
-    assert d["config"]["proofs_per_step"] == 4096 and d["value"] > 0 and "gloo" in d["config"]["exchange"]
+    ex = d["config"]["exchange"]
+    assert d["config"]["proofs_per_step"] == 4096 and d["value"] > 0 and "gloo" in ex["collectives"]
+    # the line proves from inside the group that two ranks took part (here: two processes on the one device)
+    assert ex["world_size"] == 2 and ex["backend"] == "gloo" and sorted(x["rank"] for x in ex["devices"]) == [0, 1]
+    assert len({x["pid"] for x in ex["devices"]}) == 2
 
 
 def test_bench_total_proofs_strong_scaling():

@@ -550,3 +550,57 @@ def test_emulated_poseidon_matches_plain_permutation():
     want = ob.poseidon2_permute(state)
     assert (rows[:, 409:413, :].reshape(n, 16) == want).all() and not rows[:, 413:].any()
     assert (rows[swap == 0, :12] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ PoseidonFlow
+# (source proof, how many times the circuit verifies it, the proof of that circuit): components/test_data +
+# examples/single-proof/src/main.rs:23-103, examples/multi-proofs/src/main.rs:198-295
+FLOW_CHAIN = [("small_proof.bin", 1, "recursive_proof_16_15.bin"), ("recursive_proof_16_15.bin", 5, "level1-5.bin"),
+              ("level1-5.bin", 1, "level2-1.bin"), ("level2-1.bin", 1, "level3-1.bin"), ("level3-1.bin", 5, "level4-5.bin"),
+              ("level4-5.bin", 1, "level5-1.bin"), ("level5-1.bin", 1, "level6-1.bin"), ("level6-1.bin", 1, "level7-1.bin"),
+              ("level7-1.bin", 1, "level8-1.bin"), ("level8-1.bin", 1, "level9-1.bin"), ("level9-1.bin", 1, "level10-1.bin"),
+              ("level10-1.bin", 1, "level11-1.bin"), ("level11-1.bin", 1, "level12-1.bin"), ("level12-1.bin", 1, "level13-1.bin"),
+              ("level13-1.bin", 1, "hybrid_hash.bin")]
+
+
+@pytest.mark.parametrize("src,mult,dst", FLOW_CHAIN, ids=[c[0] for c in FLOW_CHAIN])
+def test_poseidon_flow_count_predicts_next_level(src, mult, dst):
+    """The one thing the reference pins about the flow: the circuit that verifies `src` `mult` times records
+    mult x count Poseidon invocations, pads them (plonk_with_poseidon.rs:282-300) and proves them as the Poseidon
+    component of `dst`, whose log size is the second word of that fixture.  The oracle's invocation count must land on
+    it for every consecutive pair of the reference's fixtures (three of them within 4 % of a power-of-two boundary)."""
+    man = {e["file"]: e for e in load_manifest()}
+    e = man[src]
+    flow = ob.poseidon_flow(read_proof(src), [(i, tuple(v)) for i, v in e["inputs"]])
+    want = int(np.frombuffer(read_proof(dst)[:8], np.uint32)[1])
+    assert want == man[dst]["log_size_poseidon"]
+    assert ob.flow_log_size(mult * len(flow)) == want, (len(flow), mult, want)
+
+
+@pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level1-5.bin", "level13-1.bin"])
+def test_poseidon_flow_records_are_invocations(name):
+    """Every record is a Poseidon2HalfVar::permute invocation: perm(swap ? right || left : left || right) = rate || cap
+    (what check_poseidon_invocations asserts, plonk_with_poseidon.rs:468-519); the transcript part is the channel chain
+    (each mix's capacity is the next record's right half); the flow ends in the paths' roots = the commitments."""
+    e = next(x for x in load_manifest() if x["file"] == name)
+    proof = read_proof(name)
+    flow = ob.poseidon_flow(proof, [(i, tuple(v)) for i, v in e["inputs"]])
+    left, right, out, swap = flow[:, 0:8], flow[:, 8:16], flow[:, 16:32], flow[:, 32]
+    assert set(swap.tolist()) <= {0, 1} and (flow[:, :32] < 0x7FFFFFFF).all()
+    state = np.where(swap[:, None] == 1, np.concatenate([right, left], 1), np.concatenate([left, right], 1))
+    assert np.array_equal(ob.poseidon2_permute(state), out)
+    words = np.frombuffer(proof, np.uint32)
+    # record 0 = mix_root(commitment 0) on the zero digest; record 1 = mix_one_felt(lp) on its capacity
+    assert left[0].tolist() == words[17:25].tolist() and not right[0].any()
+    assert right[1].tolist() == out[0, 8:16].tolist() and left[1].tolist() == [e["log_size_plonk"]] + [0] * 7
+    # the first trace-tree path ends in commitment 0: its last record's rate
+    nq, lay = e["n_queries"], ob.proof_layout(proof)
+    n_transcript = 4 + 1 + 2 + 1 + 1 + 1 + 71 + 1 + 2 * (1 + lay["n_inner"]) + (1 << e["log_last_layer_degree_bound"]) // 2 + (
+        1 if e["log_last_layer_degree_bound"] == 0 else 0) + 1 + (nq + 3) // 4
+    A, B = e["log_size_plonk"] + e["log_blowup_factor"], e["log_size_poseidon"] + e["log_blowup_factor"]
+    lo, hi = (10, 40) if A < B else (40, 10)  # tree 0: columns at the lower / the leaf level
+    per_path0 = -(-hi // 8) + 1 + max(A, B) + (0 if A == B else -(-lo // 8) + 1)
+    if A == B:
+        per_path0 = -(-50 // 8) + 1 + A
+    assert out[n_transcript + per_path0 - 1, :8].tolist() == words[17:25].tolist()
+    assert swap[:n_transcript].sum() == 0

@@ -38,8 +38,8 @@ def main():
     for label, env, thr in (("warm_512MB", "512", "8"), ("pipelined_128MB_8t", "128", "8"), ("pipelined_256MB_8t", "256", "8"),
                             ("pipelined_256MB_16t", "256", "16"), ("pipelined_256MB_4t", "256", "4"),
                             ("pipelined_512MB_8t", "512", "8"), ("pipelined_512MB_16t", "512", "16")):
-        os.environ["RSV_HOST_CHUNK_MB"] = env
-        os.environ["RSV_HOST_THREADS"] = thr
+        ctx.set_option("host_chunk_mb", int(env))
+        ctx.set_option("host_threads", int(thr))
         acc[:] = 0
         t0 = time.perf_counter()
         rc = rsv.lib.rsv_verify_batch_host(ctx._h, ptrs, lens.ctypes.data_as(u64p), n, pc.ref(), pi, 3, acc.ctypes.data_as(u8p), None)

@@ -20,7 +20,7 @@ d_in = torch.randint(0, 0x7FFFFFFF, (m, 16), dtype=torch.int32, device=dev, gene
 d_out = torch.empty_like(d_in)
 ctx = rsv.Context(0)
 for wg in os.environ.get("PERM_WG_LIST", "4").split(","):
-    os.environ["RSV_PERM_WG_PER_CU"] = wg
+    ctx.set_option("perm_wg_per_cu", int(wg))
     ctx.poseidon2_permute(d_in, d_out)
     ctx.synchronize()
     best = 1e9
