@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--emit-paths", action="store_true",
                     help="also emit every hint output (transcript rows, trace-tree and FRI per-query paths; SURVEY 8f.1) from the "
                          "verifying pass; needs a uniform-shape workload")
+    ap.add_argument("--emit-flow", action="store_true",
+                    help="also emit the PoseidonFlow of every proof's verification circuit (SURVEY 8f.1, second half: 128 B + "
+                         "1 B per Poseidon invocation, ~0.7 MB per standard proof) from the verifying pass; any workload")
     args = ap.parse_args()
 
     # ---- plain `python bench.py --gpus N`: start the N ranks as child processes and wait.  This process loads neither
@@ -251,6 +254,16 @@ def main():
                      d_fri_sib=torch.zeros((n, 1 + p_inner, p_nq, p_M, 8), dtype=torch.int32, device=dev),
                      d_fri_cols=torch.zeros((n, 1 + p_inner, p_nq, 3, 8), dtype=torch.int32, device=dev),
                      d_fri_folded=torch.zeros((n, 3, p_nq, 4), dtype=torch.int32, device=dev))
+
+    if args.emit_flow:
+        stride = 0
+        for f in fixtures:
+            hdr = np.frombuffer(read_fixture(f)[:64], dtype=np.uint32)
+            stride = max(stride, rsv.poseidon_flow_count(int(hdr[0]), int(hdr[1]), rsv.PcsConfig(int(hdr[10]), int(hdr[11]), int(hdr[12]), int(hdr[13]))))
+        hints = dict(hints or {})
+        hints.update(d_flow=torch.empty((n, stride, 32), dtype=torch.int32, device=dev),
+                     d_flow_swap=torch.empty((n, stride), dtype=torch.uint8, device=dev),
+                     d_flow_count=torch.zeros(n, dtype=torch.int32, device=dev))
 
     # --inflight K: K - 1 further contexts with their own copy of the batch and of the outputs, driven by K - 1 threads
     extra = []
@@ -468,6 +481,8 @@ def main():
                                     "bit-exact accept map of the whole job checked on every rank",
                    "proofs_per_step": n_total * args.inflight, "proofs_rank0": n, "bytes_rank0": total_bytes, "parallelism": f"shard{world}",
                    "batches_in_flight": args.inflight,
+                   "hint_outputs": sorted(k for k in (hints or {}) if k.startswith("d_")),
+                   "flow_bytes_per_step_rank0": (int(hints["d_flow"].numel()) * 4 + int(hints["d_flow_swap"].numel())) if args.emit_flow else 0,
                    "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
                        "gloo (rehearsal)" if rehearsal else ("nccl/RCCL" if world > 1 else "none (1 rank)")))},
         "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "valu": valu, "emulated_poseidon2": emulated,

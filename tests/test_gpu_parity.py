@@ -1218,3 +1218,53 @@ def test_qconst_kernels_row_and_lane(rsv, manifest, knobs, mode):
         assert int(d_acc.item()) == 1
         assert np.array_equal(d_qv.cpu().numpy().view(np.uint32)[0], ob.query_dump(proof, entry_inputs(entry))), name
         ctx.close()
+
+
+FLOW_SHAPES = ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level1-5.bin", "level9-1.bin", "level13-1.bin"]
+
+
+@pytest.mark.parametrize("name", FLOW_SHAPES)
+def test_poseidon_flow_matches_oracle(rsv, manifest, name):
+    """SURVEY 8f.1, second half: the PoseidonFlow records the verifying pass writes (rsv_hints_out::d_flow) == the
+    oracle's, which runs the reference's per-path verifiers in the circuit's invocation order with a recorder on its
+    permutation (oracle/rsv_oracle.c: rsvo_poseidon_flow).  Seven shapes: n_queries 8 / 11 / 16 / 27 / 80, equal and
+    unequal column log sizes (level7-1: lp = lq, two column levels instead of three).  Every record is an invocation
+    (perm(inputs) = outputs, checked on the GPU's own permutation entry point) and the count is the shape's."""
+    entry = next(e for e in manifest if e["file"] == name)
+    proof, inputs, cfg = read_proof(name), entry_inputs(entry), fixture_cfg(name)
+    want = ob.poseidon_flow(proof, inputs)
+    cnt = rsv.poseidon_flow_count(entry["log_size_plonk"], entry["log_size_poseidon"], cfg)
+    assert cnt == len(want)
+    flow, swap, count, acc, reason = rsv.poseidon_flow([proof, ob.tamper(proof, 3), proof], cfg, cnt + 5, inputs)
+    assert acc.tolist() == [1, 0, 1] and count.tolist() == [cnt, cnt, cnt]
+    for k in (0, 2):
+        assert np.array_equal(flow[k, :cnt], want[:, :32]), int(np.nonzero((flow[k, :cnt] != want[:, :32]).any(axis=1))[0][0])
+        assert np.array_equal(swap[k, :cnt], want[:, 32].astype(np.uint8))
+        assert not flow[k, cnt:].any() and not swap[k, cnt:].any()
+    left, right, out = flow[0, :cnt, 0:8], flow[0, :cnt, 8:16], flow[0, :cnt, 16:32]
+    state = np.where(swap[0, :cnt, None] == 1, np.concatenate([right, left], 1), np.concatenate([left, right], 1))
+    assert np.array_equal(rsv.poseidon2_permute(state), out)
+    # a stride one record too small: the proof is still verified, nothing is written, its count says 0
+    flow1, swap1, count1, acc1, _ = rsv.poseidon_flow([proof], cfg, cnt - 1, inputs)
+    assert acc1.tolist() == [1] and count1.tolist() == [0] and not flow1.any() and not swap1.any()
+
+
+def test_poseidon_flow_mixed_batch_and_count_pin(rsv, manifest):
+    """One mixed batch (five shapes, a tampered and a garbage proof between them): per-proof counts and records, and the
+    count pin of tests/test_oracle.py::test_poseidon_flow_count_predicts_next_level from the GPU's side: the flow of
+    level K's verification, padded, is the Poseidon trace whose log size level K+1's header carries."""
+    names = ["recursive_proof_16_15.bin", "level8-1.bin", "level12-1.bin", "level3-1.bin", "level10-1.bin"]
+    proofs = [read_proof(x) for x in names]
+    batch = proofs[:2] + [ob.tamper(proofs[0], 9), b"\x00" * 4000] + proofs[2:]
+    cfgs = [fixture_cfg(x) for x in names[:2]] + [fixture_cfg(names[0])] * 2 + [fixture_cfg(x) for x in names[2:]]
+    stride = 6000
+    flow, swap, count, acc, reason = rsv.poseidon_flow(batch, cfgs, stride)
+    assert acc.tolist() == [1, 1, 0, 0, 1, 1, 1] and count[3] == 0 and reason[3] == 1
+    for k, x in zip([0, 1, 4, 5, 6], names):
+        want = ob.poseidon_flow(read_proof(x))
+        assert count[k] == len(want) and np.array_equal(flow[k, :len(want)], want[:, :32]) and np.array_equal(swap[k, :len(want)], want[:, 32])
+    nxt = {"recursive_proof_16_15.bin": (5, "level1-5.bin"), "level8-1.bin": (1, "level9-1.bin"), "level12-1.bin": (1, "level13-1.bin"),
+           "level3-1.bin": (5, "level4-5.bin"), "level10-1.bin": (1, "level11-1.bin")}
+    for k, x in zip([0, 1, 4, 5, 6], names):
+        mult, dst = nxt[x]
+        assert ob.flow_log_size(mult * int(count[k])) == next(e for e in manifest if e["file"] == dst)["log_size_poseidon"]
