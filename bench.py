@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--emit-paths", action="store_true",
                     help="also emit every hint output (transcript rows, trace-tree and FRI per-query paths; SURVEY 8f.1) from the "
                          "verifying pass; needs a uniform-shape workload")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiments only: a tuning knob of the library (rsv_ctx_set_option, names in rsv.OPTIONS), e.g. "
+                         "critical_chain=off.  The bench line is measured with none.")
     ap.add_argument("--emit-flow", action="store_true",
                     help="also emit the PoseidonFlow of every proof's verification circuit (SURVEY 8f.1, second half: 128 B + "
                          "1 B per Poseidon invocation, ~0.7 MB per standard proof) from the verifying pass; any workload")
@@ -225,6 +228,9 @@ def main():
     rehearsal = os.environ.get("RSV_BENCH_REHEARSAL") == "1"
     if torch.cuda.device_count() < (1 if rehearsal else world_env):
         raise SystemExit("bench.py needs one HIP device per rank: the product has no CPU fallback")
+    for kv in args.knob:
+        name, value = kv.split("=", 1)
+        rsv.set_default_option(name, value if value in rsv.OPTION_VALUES else int(value))
     rank, world, dev_index = sharding.init_rank(torch, dist, rehearsal)
     if rsv.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
@@ -480,7 +486,7 @@ def main():
         "config": {"workload": wl + ", i%17==5 tampered (SURVEY §8d), full verify under the reference's PcsConfig literals; "
                                     "bit-exact accept map of the whole job checked on every rank",
                    "proofs_per_step": n_total * args.inflight, "proofs_rank0": n, "bytes_rank0": total_bytes, "parallelism": f"shard{world}",
-                   "batches_in_flight": args.inflight,
+                   "batches_in_flight": args.inflight, "knobs": args.knob,
                    "hint_outputs": sorted(k for k in (hints or {}) if k.startswith("d_")),
                    "flow_bytes_per_step_rank0": (int(hints["d_flow"].numel()) * 4 + int(hints["d_flow_swap"].numel())) if args.emit_flow else 0,
                    "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (

@@ -150,7 +150,9 @@ typedef enum rsv_option {
     RSV_OPT_HOST_CHUNK_MB = 10,   /* 1 .. 16384: staging chunk of rsv_verify_batch_host (default 256) */
     RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 8), else 1 .. 64 gather threads of rsv_verify_batch_host */
     RSV_OPT_DEBUG_LOG = 12,       /* 0 / 1: print failing HIP calls to stderr (process-wide, ctx ignored) */
-    RSV_OPT_CRITICAL_CHAIN = 13   /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
+    RSV_OPT_CRITICAL_CHAIN = 13,  /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
+    RSV_OPT_DEVICE_ORDER = 14     /* 0 / 1 batches under one configuration: slot order by shape on the device, no host round
+                                     trip inside the call; 2 the host-side bucketing of multi-configuration batches */
 } rsv_option;
 int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 
@@ -290,10 +292,16 @@ int rsv_verify_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
                      const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi,
                      uint8_t* accept, uint8_t* reason, int device);
 
-/* Same, inputs and outputs resident in HBM (d_ = device pointers); enqueued on
- * ctx's stream, returns without synchronising.  d_offsets must be 8-byte
- * aligned, d_blob 4-byte aligned and every offset a multiple of 4 (bincode
- * proofs of this type always have 4-byte-multiple lengths). */
+/* Same, inputs and outputs resident in HBM (d_ = device pointers); enqueued on ctx's streams.  d_offsets must be 8-byte
+ * aligned, d_blob 4-byte aligned and every offset a multiple of 4 (bincode proofs of this type always have
+ * 4-byte-multiple lengths).
+ * Host synchronisation: a batch under ONE configuration (cfg->n_cfgs == 1, cfg_of NULL) is enqueued completely and the
+ * call returns without waiting for the device (after the first call has grown the workspaces).  A batch under several
+ * configurations is bucketed by n_queries on the host: the call waits for the parser (a few hundred microseconds),
+ * reads 8 bytes per proof back, and enqueues the rest; so do the calls with per-query path outputs
+ * (rsv_trace_paths_dev, rsv_fri_paths_dev, the path / query-value outputs of rsv_verify_hints_dev), whose declared
+ * shape is checked on the host.  Either way the verdicts are complete only after rsv_ctx_synchronize /
+ * rsv_stream_wait_ctx. */
 int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets,
                          size_t n, const rsv_cfg_set* cfg, const rsv_public_input* pi,
                          size_t n_pi, uint8_t* d_accept, uint8_t* d_reason);
@@ -406,6 +414,11 @@ typedef struct {
     uint8_t* d_flow_swap;
     uint32_t* d_flow_count;
     uint32_t flow_stride;
+    /* the batch's accept bitmap and count from the verifying pass (ABI v3): what rsv_accept_bitmap_dev computes from
+     * the accept bytes, written by the kernel that writes the verdicts (one launch less on the latency path of a
+     * small batch).  d_accept_bitmap: ceil(n/32) words; d_accept_count: optional u64, needs d_accept_bitmap. */
+    uint32_t* d_accept_bitmap;
+    uint64_t* d_accept_count;
 } rsv_hints_out;
 int rsv_verify_hints_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, const rsv_hints_out* out, uint8_t* d_accept,

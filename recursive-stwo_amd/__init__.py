@@ -120,7 +120,7 @@ class HintsOut(ctypes.Structure):  # rsv_hints_out
                 ("d_trace_cols", ctypes.c_void_p), ("d_fri_sib", ctypes.c_void_p), ("d_fri_cols", ctypes.c_void_p),
                 ("d_fri_folded", ctypes.c_void_p), ("d_query_values", ctypes.c_void_p),
                 ("d_flow", ctypes.c_void_p), ("d_flow_swap", ctypes.c_void_p), ("d_flow_count", ctypes.c_void_p),
-                ("flow_stride", ctypes.c_uint32)]
+                ("flow_stride", ctypes.c_uint32), ("d_accept_bitmap", ctypes.c_void_p), ("d_accept_count", ctypes.c_void_p)]
 
 
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
@@ -223,8 +223,8 @@ def device_count() -> int:
 #: rsv_option (include/rsv.h) by name, and the named values of the three-way knobs (0 is always "automatic")
 OPTIONS = {"transcript_form": 1, "transcript_split": 2, "oods_form": 3, "qconst_form": 4, "plan_form": 5, "tree_cap": 6,
            "overlap_trees": 7, "ws_budget_mb": 8, "perm_wg_per_cu": 9, "host_chunk_mb": 10, "host_threads": 11, "debug_log": 12,
-           "critical_chain": 13}
-OPTION_VALUES = {"auto": 0, "row": 1, "lane": 2, "whole": 1, "split": 2, "parallel": 1, "serial": 2, "on": 1, "off": 2}
+           "critical_chain": 13, "device_order": 14}
+OPTION_VALUES = {"auto": 0, "row": 1, "lane": 2, "whole": 1, "split": 2, "parallel": 1, "serial": 2, "on": 1, "off": 2, "device": 1, "host": 2}
 
 
 def _set_option(handle, name: str, value) -> None:
@@ -478,7 +478,8 @@ def poseidon_flow(proofs: Sequence[bytes], cfg, flow_stride: int, inputs=STANDAR
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
     pi = make_inputs(inputs)
-    ho = HintsOut(0, 0, 0, None, None, None, None, None, None, None, None, flow.ctypes.data, swap.ctypes.data, count.ctypes.data, flow_stride)
+    ho = HintsOut(0, 0, 0, None, None, None, None, None, None, None, None, flow.ctypes.data, swap.ctypes.data, count.ctypes.data, flow_stride,
+                  None, None)
     _check(lib.rsv_verify_hints(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), pi, len(list(inputs)),
                                 ctypes.byref(ho), accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_verify_hints")
     return flow, swap, count, accept, reason
@@ -625,13 +626,15 @@ class Context:
 
     def verify_hints(self, d_blob, d_offsets, n: int, d_accept, d_reason=None, cfg=None, inputs=STANDARD_INPUTS, shape=(0, 0, 0),
                      d_transcript=None, d_trace_sib=None, d_trace_pos=None, d_trace_cols=None, d_fri_sib=None,
-                     d_fri_cols=None, d_fri_folded=None, d_query_values=None, d_flow=None, d_flow_swap=None, d_flow_count=None):
+                     d_fri_cols=None, d_fri_folded=None, d_query_values=None, d_flow=None, d_flow_swap=None, d_flow_count=None,
+                     d_accept_bitmap=None, d_accept_count=None):
         """One verifying pass that also fills whichever hint outputs are given (rsv_verify_hints_dev).
         shape = (n_queries, max_log, n_inner), needed for the path outputs."""
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         ho = HintsOut(int(shape[0]), int(shape[1]), int(shape[2]), ptr(d_transcript), ptr(d_trace_sib), ptr(d_trace_pos),
                       ptr(d_trace_cols), ptr(d_fri_sib), ptr(d_fri_cols), ptr(d_fri_folded), ptr(d_query_values),
-                      ptr(d_flow), ptr(d_flow_swap), ptr(d_flow_count), int(d_flow.shape[1]) if d_flow is not None else 0)
+                      ptr(d_flow), ptr(d_flow_swap), ptr(d_flow_count), int(d_flow.shape[1]) if d_flow is not None else 0,
+                      ptr(d_accept_bitmap), ptr(d_accept_count))
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(cfg, n)
         self.acquire_from_torch()

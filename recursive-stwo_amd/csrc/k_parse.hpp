@@ -1,4 +1,4 @@
-// k_parse.hpp — wire-format walk (k_parse) and the canonicity fallback scan (k_rescan).  Part of the pipeline described in verify.hpp.
+// k_parse.hpp — wire-format walk (k_parse) and the canonicity fallback scan (scan_proof_words).  Part of the pipeline described in verify.hpp.
 #pragma once
 #include "verify_common.hpp"
 
@@ -125,52 +125,132 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     atomicMax(&summary[7], ~sw2);
 }
 
-// ----------------------------------------------------------------- k_rescan
-// Canonicity fallback (layout.hpp, F_RESCAN): a proof in which some stage found a witness list of the wrong length —
-// already rejected by that stage — is read once in full here, so that a non-canonical word in the part of the list
-// nobody consumed still gives RSV_R_PARSE, the reason include/rsv.h defines for it.  Every field element of a proof must be a
+// ------------------------------------------------------------- slot order on the device
+// Inside one launch geometry (one n_queries bucket) the slots are ordered by SHAPE CLASS — the two shape words k_parse
+// writes: (n_queries, M, n_inner, lowest level | A, B) — so that the lanes of a wavefront, and nearly every workgroup,
+// walk trees of one geometry (the multi-proofs standard configuration mixes three: a wavefront of the Merkle kernels
+// that holds several runs every column-level call site once per geometry with most lanes masked; ordering the slots
+// was worth 11 % in round 1).  Rounds 1-2 did this on the host: 8 bytes per proof read back, a counting sort, one index
+// list uploaded — a host round trip in the middle of every call (the row hashes of a 65 536-proof batch started
+// 0.4 ms late because of it, and the call could not return before the parser had finished).  For a batch under ONE
+// configuration (one n_queries, so one bucket of known size) three small kernels do it instead:
+//   k_classify       find-or-insert every proof's shape words in a 64-entry table (atomicCAS), count the classes
+//   k_class_offsets  one wave: order the classes by their shape words, exclusive scan of the counts
+//   k_scatter_ids    ids[start[class] + rank] = proof; rank from a wave-aggregated atomic cursor
+// Unparsed proofs form a class of their own (their lanes are not live anywhere).  More than 63 distinct shapes in one
+// batch (only an adversary builds that) share the last class: still correct, merely mixed.  The order inside a class is
+// not deterministic; every proof of a class has the same geometry and every output is addressed by proof, not by slot.
+constexpr uint32_t N_CLASSES = 64;
+struct ClassTable {
+    unsigned long long key[N_CLASSES];  // w0 << 32 | w1, 0 = free; entry N_CLASSES - 1 doubles as the overflow class
+    uint32_t count[N_CLASSES];
+    uint32_t start[N_CLASSES];
+    uint32_t cursor[N_CLASSES];
+    uint32_t unparsed;                   // proofs the parser rejected: the last slots
+    uint32_t unparsed_cursor;
+};
+
+__global__ __launch_bounds__(256) void k_classify(uint32_t n, const uint32_t* __restrict__ shape, ClassTable* __restrict__ tab,
+                                                  uint8_t* __restrict__ cls) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0xFFu;  // unparsed
+    if (p < n && shape[2 * p]) {
+        const unsigned long long k = ((unsigned long long)shape[2 * p] << 32) | shape[2 * p + 1];
+        // open addressing from a hash of the key; the table is all but empty (a handful of shapes per batch)
+        uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 58);
+        c = N_CLASSES - 1;
+        for (uint32_t probe = 0; probe < N_CLASSES - 1; probe++, h = (h + 1) % (N_CLASSES - 1)) {
+            unsigned long long cur = tab->key[h];
+            if (cur == 0) cur = atomicCAS(&tab->key[h], 0ull, k);
+            if (cur == 0 || cur == k) { c = h; break; }
+        }
+    }
+    if (p < n) cls[p] = (uint8_t)c;
+    // per-class counts, one atomic per class and wave
+    unsigned long long todo = __ballot(p < n);
+    const uint32_t lane = threadIdx.x & 63;
+    while (todo) {
+        const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t cc = (uint32_t)__shfl((int)c, (int)lead);
+        const unsigned long long same = __ballot(p < n && c == cc);
+        if (lane == lead) {
+            if (cc == 0xFFu) atomicAdd(&tab->unparsed, (uint32_t)__popcll(same));
+            else atomicAdd(&tab->count[cc], (uint32_t)__popcll(same));
+        }
+        todo &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_class_offsets(ClassTable* __restrict__ tab) {
+    // lane i owns table entry i: its start = the counts of all entries whose key sorts before its own (ties cannot
+    // happen: keys are distinct; the overflow entry has key 0 = sorts first, which is as good a place as any)
+    const uint32_t i = threadIdx.x;
+    const unsigned long long mine = tab->key[i];
+    uint32_t start = 0;
+    for (uint32_t j = 0; j < N_CLASSES; j++) {
+        const unsigned long long kj = tab->key[j];
+        if (kj < mine || (kj == mine && j < i)) start += tab->count[j];
+    }
+    tab->start[i] = start;
+    tab->cursor[i] = 0;
+    if (i == 0) tab->unparsed_cursor = 0;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_ids(uint32_t n, const uint8_t* __restrict__ cls, ClassTable* __restrict__ tab,
+                                                     uint32_t* __restrict__ ids) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = p < n ? cls[p] : 0xFEu;
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(p < n);
+    while (todo) {
+        const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t cc = (uint32_t)__shfl((int)c, (int)lead);
+        const unsigned long long same = __ballot(p < n && c == cc);
+        uint32_t base = 0;
+        if (lane == lead) {
+            const uint32_t k = (uint32_t)__popcll(same);
+            // unparsed proofs: behind every class (n - unparsed .. n), from a cursor of their own (start[] is unused for them)
+            base = cc == 0xFFu ? n - tab->unparsed + atomicAdd(&tab->unparsed_cursor, k) : tab->start[cc] + atomicAdd(&tab->cursor[cc], k);
+        }
+        base = (uint32_t)__shfl((int)base, (int)lead);
+        if (p < n && c == cc) ids[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = p;
+        todo &= ~same;
+    }
+}
+
+// ------------------------------------------------------------- canonicity fallback
+// (layout.hpp, F_RESCAN): a proof in which some stage found a witness list of the wrong length — already rejected by
+// that stage — is read once in full (by k_finalize), so that a non-canonical word in the part of the list nobody consumed
+// still gives RSV_R_PARSE, the reason include/rsv.h defines for it.  Every field element of a proof must be a
 // canonical M31 word (< P); exempt are the words that are not field elements and that nothing else constrains: the
 // two halves of the proof-of-work nonce, and the proof's final word, last_layer_poly.log_size — the reference never
 // reads it (it takes the size from coeffs.len(), components/hints/src/folding.rs:573, fiat_shamir.rs:196-200), so any
-// u32 there verifies.  One lane looks at one proof's flag; the wave then reads the flagged proofs of its 64 one after
-// the other with 16-byte coalesced loads.  In a batch of well-formed and bit-flipped proofs nothing is flagged and the
-// kernel reads 8 bytes per proof (rounds 1-2 read every proof a second time: 7.7 GB per 65 536-proof step).
-// force: every parsed proof is read (the single-proof probe rsv_transcript, which runs no Merkle stage).
-__global__ __launch_bounds__(256) void k_rescan(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                                                uint32_t n, const ProofMeta* __restrict__ metas,
-                                                ProofCtx* __restrict__ ctxs, uint32_t force) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool want = mine < n && metas[mine].reason == R_OK && (force || (ctxs[mine].flags & F_RESCAN));
-    unsigned long long todo = __ballot(want);
-    while (todo) {
-        const uint32_t src = (uint32_t)__ffsll((long long)todo) - 1u;
-        todo &= todo - 1ull;
-        const uint32_t p = mine - lane + src;
-        const ProofMeta& m = metas[p];
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
-        const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
-        auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
-        uint32_t bad = 0;
-        // align the vector loop to 16 bytes
-        uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
-        head = umin(head, nw);
-        if (lane < head) bad |= (w[lane] >= P) && !exempt(lane);
-        const uint4* v = reinterpret_cast<const uint4*>(w + head);
-        uint32_t nv = (nw - head) >> 2;
-        for (uint32_t i = lane; i < nv; i += 64) {
-            uint4 x = v[i];
-            uint32_t base = head + 4 * i;
-            uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
-            if (o) {
-                for (int k = 0; k < 4; k++)
-                    if (((o >> k) & 1) && !exempt(base + k)) bad = 1;
-            }
+// u32 there verifies.  Wave-cooperative: all 64 lanes call it for the SAME proof and read it with 16-byte coalesced
+// loads; returns non-zero (on every lane) when a non-exempt word is not canonical.
+__device__ inline uint32_t scan_proof_words(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                                            const ProofMeta& m, uint32_t p, uint32_t lane) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    const uint32_t nw = m.n_words, nonce = m.nonce_off, last = nw - 1;  // k_parse ends exactly on the final word
+    auto exempt = [&](uint32_t i) { return i == nonce || i == nonce + 1 || i == last; };
+    uint32_t bad = 0;
+    // align the vector loop to 16 bytes
+    uint32_t head = (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) >> 2);
+    head = umin(head, nw);
+    if (lane < head) bad |= (w[lane] >= P) && !exempt(lane);
+    const uint4* v = reinterpret_cast<const uint4*>(w + head);
+    uint32_t nv = (nw - head) >> 2;
+    for (uint32_t i = lane; i < nv; i += 64) {
+        uint4 x = v[i];
+        uint32_t base = head + 4 * i;
+        uint32_t o = (x.x >= P) | ((x.y >= P) << 1) | ((x.z >= P) << 2) | ((x.w >= P) << 3);
+        if (o) {
+            for (int k = 0; k < 4; k++)
+                if (((o >> k) & 1) && !exempt(base + k)) bad = 1;
         }
-        uint32_t tail = head + 4 * nv;
-        if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
-        if (__any(bad) && lane == 0) atomicOr(&ctxs[p].flags, 1u << R_PARSE);
     }
+    uint32_t tail = head + 4 * nv;
+    if (tail + lane < nw) bad |= (w[tail + lane] >= P) && !exempt(tail + lane);
+    return __any(bad) ? 1u : 0u;
 }
 
 }  // namespace rsv

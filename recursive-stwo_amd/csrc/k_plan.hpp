@@ -30,9 +30,12 @@ constexpr int MAX_FUSED = 8;
 template <class Args>
 struct Fused {
     uint32_t nb;
+    uint32_t lds_proofs;                  // k_plan_par: proofs per workgroup its dynamic LDS tables are sized for
     uint32_t first_block[MAX_FUSED + 1];  // first blockIdx.x of set i; [nb] = grid size
     Args a[MAX_FUSED];
 };
+// dynamic LDS of k_plan_par for workgroups of up to `proofs` proofs
+constexpr size_t plan_lds_bytes(uint32_t proofs) { return (size_t)proofs * (32 * 2 * 8 + 3 * 32 * 4); }
 // workgroup-uniform: the argument set of this block and its block index inside that set
 #define RSV_FUSED_SELECT(FUSED_, ARGS_, BX_)                                                            \
     uint32_t fused_i_ = 0;                                                                               \
@@ -219,13 +222,19 @@ __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ 
     RSV_FUSED_SELECT(f, pa, bx);
     const uint32_t n = pa.n;
     const PlanPtrs& pl = pa.pl;
-    __shared__ unsigned long long F[64][32][2];   // per_block <= 64 proofs, levels 0..30
+    // Per-proof tables in DYNAMIC LDS, sized by the launch for the proofs a workgroup really holds (BLOCK / G: 16 for
+    // 16-query proofs): 896 bytes per proof.  As static arrays for the worst case (64 proofs of 4 lanes) they took 59 KB,
+    // two workgroups per CU, and the kernel — alone on the chip between the transcript and the trace trees — ran a
+    // 65 536-proof batch in eight rounds of ~130 us; now every wave slot is filled (plan_lds_bytes()).
+    extern __shared__ unsigned long long plan_dyn[];
+    const uint32_t G = pl.G, per_block = BLOCK / G;
+    const uint32_t pb = f.lds_proofs;             // proofs per workgroup the launch sized the tables for (>= per_block)
+    unsigned long long (*F)[32][2] = reinterpret_cast<unsigned long long (*)[32][2]>(plan_dyn);  // [pb] levels 0..30
+    uint32_t (*tl)[32] = reinterpret_cast<uint32_t (*)[32]>(plan_dyn + (size_t)pb * 64);         // per level: nodes | lacking << 8
+    uint32_t (*tw)[32] = tl + pb;                 // per node level: witness weight of the first-layer pair tree
+    uint32_t (*wsum)[32] = tw + pb;               // wf[l + 1]
     __shared__ uint32_t raw[BLOCK], sq[BLOCK];
     __shared__ uint8_t sp[BLOCK];
-    __shared__ uint32_t tl[64][32];               // per level: nodes | lacking << 8
-    __shared__ uint32_t tw[64][32];               // per node level: witness weight of the first-layer pair tree
-    __shared__ uint32_t wsum[64][32];             // wf[l + 1]
-    const uint32_t G = pl.G, per_block = BLOCK / G;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot = bx * per_block + grp;
     bool livep = grp < per_block && slot < n;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ 
     const bool live = livep && j < nq;
     ProofCtx* c = livep ? &ctxs[p] : nullptr;
     const uint32_t gbase = grp * G;
-    for (uint32_t i = threadIdx.x; i < 64u * 32u * 2u; i += BLOCK) (&F[0][0][0])[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < pb * 32u * 2u; i += BLOCK) (&F[0][0][0])[i] = 0ull;
     const uint32_t v0 = live ? (c->raw_q[j] & ((1u << M) - 1u)) : 0xFFFFFFFFu;
     raw[threadIdx.x] = v0;
     __syncthreads();

@@ -41,6 +41,7 @@ struct Options {
     long long host_chunk_mb = 256;
     int host_threads = 0;      // 0 = min(cores, 8)
     int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
+    int device_order = 0;      // 0 / 1 single-configuration batches: slot order on the device, no host round trip; 2 host
 };
 static Options g_default_options;
 static std::mutex g_options_mu;
@@ -214,6 +215,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_TREE_CAP: return tri(&o.tree_cap);
         case RSV_OPT_OVERLAP_TREES: return tri(&o.overlap_trees);
         case RSV_OPT_CRITICAL_CHAIN: return tri(&o.critical_chain);
+        case RSV_OPT_DEVICE_ORDER: return tri(&o.device_order);
         case RSV_OPT_WS_BUDGET_MB:
             if (value < 1 || value > (1ll << 20)) return RSV_E_RANGE;
             o.ws_budget_mb = value; return RSV_OK;

@@ -123,8 +123,8 @@ class ShardedVerifier:
         sv.step(d_blob, d_offsets, cfg)         # this rank's shard, resident in HBM
         accept = sv.exchange.assemble()           # whole job, every rank
 
-    step() = rsv_verify_batch_dev on the shard -> rsv_accept_bitmap_dev into the exchange slice -> all-gather +
-    all-reduce.  Nothing blocks the host: the verifier's stream is ordered before torch's current stream (on which
+    step() = rsv_verify_hints_dev on the shard (verdicts + the accept bitmap and count into the exchange slice) ->
+    all-gather + all-reduce.  Nothing blocks the host: the verifier's stream is ordered before torch's current stream (on which
     the collectives are enqueued) with an event."""
 
     def __init__(self, rsv, n_total: int, rank: int, world: int, device_index: int, dist, torch):
@@ -138,11 +138,10 @@ class ShardedVerifier:
 
     def step(self, d_blob, d_offsets, cfg, inputs=None, hints=None):
         kw = {} if inputs is None else {"inputs": inputs}
-        if hints:
-            self.ctx.verify_hints(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw, **hints)
-        else:
-            self.ctx.verify_batch(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw)
-        self.ctx.accept_bitmap(self.d_accept, self.n_local, self.exchange.local, self.exchange.count)
+        # verdicts, and the rank's bitmap slice + accept count straight into the exchange buffers, from ONE pass
+        # (rsv_hints_out::d_accept_bitmap: the kernel that writes the verdicts packs them)
+        self.ctx.verify_hints(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw, **(hints or {}),
+                              d_accept_bitmap=self.exchange.local, d_accept_count=self.exchange.count)
         self.ctx.release_to_torch()
         self.exchange.run()
 

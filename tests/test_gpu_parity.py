@@ -1268,3 +1268,45 @@ def test_poseidon_flow_mixed_batch_and_count_pin(rsv, manifest):
     for k, x in zip([0, 1, 4, 5, 6], names):
         mult, dst = nxt[x]
         assert ob.flow_log_size(mult * int(count[k])) == next(e for e in manifest if e["file"] == dst)["log_size_poseidon"]
+
+
+def _reshaped(proof: bytes, lp: int, lq: int) -> bytes:
+    """The fixture re-serialized under another pair of component log sizes: header words changed, the list of inner FRI
+    layers cut or padded to the length the parser derives from them.  Parses; cannot verify."""
+    d = ob.split_variable_part(proof)
+    head = d["head"].copy()
+    head[0], head[1] = lp, lq
+    d["head"] = head
+    b, last = int(head[11]), int(head[12])
+    n_inner = max(lp + 1, lq + 2) + b - 1 - (last + b)
+    layers = d["layers"]
+    d["layers"] = [layers[0]] + [layers[1 + (i % (len(layers) - 1))] for i in range(n_inner)]
+    return ob.join_variable_part(d)
+
+
+@pytest.mark.parametrize("order", ["device", "host"])
+def test_slot_order_on_the_device_and_on_the_host(rsv, knobs, order):
+    """A batch under ONE configuration takes no host round trip: the slot order by shape class is made by three small
+    kernels (csrc/k_parse.hpp: k_classify / k_class_offsets / k_scatter_ids) and the tables are sized for the deepest
+    trees the parser admits.  The same batch through the host-side bucketing of rounds 1-2 (device_order = host) and
+    through the device path must give the oracle's verdicts: the four standard-configuration fixtures interleaved
+    (three geometries), tampered copies, garbage and truncated buffers (the unparsed class), and 150 parseable proofs of
+    ~90 DISTINCT shapes (more than the 63 entries of the class table: the overflow class)."""
+    knobs.set("device_order", order)
+    names = ["recursive_proof_16_15.bin", "level3-1.bin", "level6-1.bin", "level7-1.bin"]
+    proofs = [read_proof(x) for x in names]
+    cfg = fixture_cfg(names[0])
+    batch = []
+    for i in range(600):
+        pr = proofs[i % 4]
+        batch.append(ob.tamper(pr, i) if i % 7 == 3 else (pr[: 4000 + 4 * i] if i % 53 == 9 else pr))
+    shapes = [(lp, lq) for lp in range(9, 24) for lq in range(9, 22) if 14 <= max(lp + 1, lq + 2) + 5 <= 30][:90]
+    assert len(set(shapes)) > 63
+    for k in range(150):
+        lp, lq = shapes[k % len(shapes)]
+        batch.append(_reshaped(proofs[k % 4], lp, lq))
+    batch += [b"", b"\x00" * 8000, proofs[0]]
+    acc, reason = rsv.verify_batch(batch, cfg)
+    oacc, oreason = ob.verify_batch(batch, cfg)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
+    assert int(acc.sum()) > 400 and acc[-1] == 1 and 1 in reason.tolist() and 2 in reason.tolist()

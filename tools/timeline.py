@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Timeline of the LAST verify step in a rocprofv3 --kernel-trace CSV: kernel, stream/queue, start and end in us relative
+to the step's first kernel (k_parse or the front half of a split transcript).  Usage: python tools/timeline.py <kernel_trace.csv>"""
+import csv
+import sys
+
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rsv::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the last k_parse starts the last step (a split transcript's front half may start a little earlier)
+last_parse = max(i for i, r in enumerate(rows) if "k_parse" in r["Kernel_Name"])
+first = last_parse
+while first > 0 and "k_transcript_row<1>" in rows[first - 1]["Kernel_Name"]:
+    first -= 1
+t0 = int(rows[first]["Start_Timestamp"])
+prev_end = t0
+for r in rows[first:]:
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rsv::", "")
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+    print(f"{name:28s} q{r.get('Queue_Id', '?'):>3s} {s:9.1f} -> {e:9.1f}  ({e - s:8.1f} us)  grid {r.get('Grid_Size', '?')}")
