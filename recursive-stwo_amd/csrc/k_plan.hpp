@@ -26,7 +26,7 @@ struct PlanPtrs {
 // sets (one per bucket: its own lanes-per-proof G, tables and workspace) and a workgroup finds its set from its block
 // index.  A batch of many small buckets is then one launch per stage instead of one per bucket and stage, and the
 // buckets' tails fill with each other's workgroups.
-constexpr int MAX_FUSED = 8;
+constexpr int MAX_FUSED = 16;
 template <class Args>
 struct Fused {
     uint32_t nb;

@@ -1109,8 +1109,9 @@ def test_last_layer_check_probe(rsv):
 
 
 def test_many_distinct_query_counts_in_one_batch(rsv):
-    """More n_queries buckets than one fused launch holds (MAX_FUSED = 8): the header word n_queries of genuine proofs
-    is rewritten to twelve other values and each proof is verified under the matching configuration (16 configurations
+    """As many n_queries buckets as one call can carry (16 configurations = RSV_MAX_CFGS = MAX_FUSED since round 3: every
+    per-query stage is ONE launch over all of them; until round 2 a launch held 8): the header word n_queries of genuine
+    proofs is rewritten to twelve other values and each proof is verified under the matching configuration (16 configurations
     = RSV_MAX_CFGS in one call, 16 distinct n_queries), so every one parses, passes the
     proof of work (n_queries is not part of the transcript before it) and fails in the Merkle stages with its own
     lane geometry; genuine proofs of four shapes sit in between.  Verdict and reason == the oracle's, and a second

@@ -74,6 +74,74 @@ DEF_KERNEL(k_sub_nc, asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b
 DEF_KERNEL(k_ashr, asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i])))
 DEF_KERNEL(k_dot, asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
 
+// ---- round 3 lab list: candidate forms for fewer / cheaper instructions in the permutation
+DEF_KERNEL(k_perm, asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_dot4_u8, asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_pk_mul16, asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_pk_mad16, asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+DEF_KERNEL(k_add_sdwa, asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_add_dpp, asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_sub_clamp, asm volatile("v_sub_u32 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_cvt_f64_u32, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(w[i]) : "v"(a[i])))
+DEF_KERNEL(k_cvt_u32_f64, asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(a[i]) : "v"(w[i])))
+DEF_KERNEL(k_min_f32, asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL(k_lshl_or, asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b)))
+
+// MFMA rows: one MFMA per "instruction" of the generic harness (8 independent accumulators per wave).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mfma_i8(uint32_t* out, uint32_t seed) {
+    v4i acc[CHAINS];
+    for (int i = 0; i < CHAINS; i++) acc[i] = v4i{(int)seed, 1, 2, (int)threadIdx.x};
+    const int a = (int)(threadIdx.x * 2654435761u), b = (int)seed | 1;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < CHAINS; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a * 0x100000001L, (long)b * 0x100000001L, acc[i], 0, 0, 0);
+    }
+    int r = 0;
+    for (int i = 0; i < CHAINS; i++) r ^= acc[i][0] ^ acc[i][1] ^ acc[i][2] ^ acc[i][3];
+    if (r == 0x12345678) out[0] = (uint32_t)r;
+}
+__global__ __launch_bounds__(256) void k_mfma_f64(uint32_t* out, uint32_t seed) {
+    v4d acc[CHAINS];
+    for (int i = 0; i < CHAINS; i++) acc[i] = v4d{(double)seed, 1.0, 2.0, (double)threadIdx.x};
+    const double a = (double)threadIdx.x, b = (double)(seed | 1);
+    for (int it = 0; it < ITERS / 4; it++) {
+#pragma unroll
+        for (int i = 0; i < CHAINS; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double r = 0;
+    for (int i = 0; i < CHAINS; i++) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (r == 0.12345678) out[0] = 1;
+}
+// Does the matrix pipe run BESIDE the VALU?  Odd workgroups issue only v_add_u32, even ones only MFMA i8: with the same
+// total wave count as the pure rows, the time of this row against max(pure VALU, pure MFMA) / their sum tells.
+__global__ __launch_bounds__(256) void k_mix_mfma_valu(uint32_t* out, uint32_t seed) {
+    if (blockIdx.x & 1) {
+        uint32_t a[CHAINS];
+        uint32_t b = seed | 1u;
+        for (int i = 0; i < CHAINS; i++) a[i] = threadIdx.x * 2654435761u + i + seed;
+        for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+            for (int i = 0; i < CHAINS; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        }
+        uint32_t r = 0;
+        for (int i = 0; i < CHAINS; i++) r ^= a[i];
+        if (r == 0x12345678u) out[0] = r;
+    } else {
+        v4i acc[CHAINS];
+        for (int i = 0; i < CHAINS; i++) acc[i] = v4i{(int)seed, 1, 2, (int)threadIdx.x};
+        const int a = (int)(threadIdx.x * 2654435761u), b = (int)seed | 1;
+        for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+            for (int i = 0; i < CHAINS; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a * 0x100000001L, (long)b * 0x100000001L, acc[i], 0, 0, 0);
+        }
+        int r = 0;
+        for (int i = 0; i < CHAINS; i++) r ^= acc[i][0] ^ acc[i][1] ^ acc[i][2] ^ acc[i][3];
+        if (r == 0x12345678) out[0] = (uint32_t)r;
+    }
+}
+
 // what hipcc emits behind an inline-asm statement whose result the next instruction reads (dst-sel forwarding hazard
 // assumed for opaque asm on gfx940+): the same instruction followed by s_nop 0
 DEF_KERNEL(k_add_nop, asm volatile("v_add_u32 %0, %0, %1\n\ts_nop 0" : "+v"(a[i]) : "v"(b)))
@@ -130,6 +198,11 @@ int main(int argc, char** argv) {
                     {"v_add_lshl_u32", k_add_lshl}, {"v_med3_u32", k_med3}, {"v_min3_u32", k_min3}, {"cmp+cndmask (2)", k_cmp_cnd},
                     {"sub_co+cndmask (2)", k_sub_co_cnd}, {"v_addc_co_u32", k_addc}, {"v_add_u32 sgpr", k_add_s}, {"v_add_u32 literal", k_add_lit},
                     {"v_and_b32 literal", k_and_lit}, {"v_min_u32 literal", k_min_lit}, {"v_mad_u64_u32 sgpr", k_mad64_s}, {"v_mul_lo self", k_mul_lo_2dep}, {"v_mad_i32_i24", k_dot},
+                    {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4_u8}, {"v_pk_mul_lo_u16", k_pk_mul16}, {"v_pk_mad_u16", k_pk_mad16},
+                    {"v_add_u32_sdwa WORD_1", k_add_sdwa}, {"v_add_u32_dpp quad_perm", k_add_dpp}, {"v_sub_u32 clamp", k_sub_clamp},
+                    {"v_cvt_f64_u32", k_cvt_f64_u32}, {"v_cvt_u32_f64", k_cvt_u32_f64}, {"v_min_f32", k_min_f32}, {"v_lshl_or_b32", k_lshl_or},
+                    {"MFMA i32_16x16x32_i8", k_mfma_i8}, {"MFMA f64_16x16x4 (x1/4 iters)", k_mfma_f64},
+                    {"MIX half waves v_add / half MFMA i8", k_mix_mfma_valu},
                     {"v_add_u32 + s_nop", k_add_nop}, {"v_mad_u64_u32(acc) + s_nop", k_mad64_acc_nop}, {"v_lshl_add_u64 + s_nop", k_lshl_add64_nop},
                     {"chain of 5", k_chain}, {"chain of 5 + 2 s_nop", k_chain_nop},
                     {"DEP v_add_u32", d_add}, {"DEP v_add_u32 + s_nop 0", d_add_n0}, {"DEP v_add_u32 + s_nop 1", d_add_n1}, {"DEP v_add_u32 + s_nop 3", d_add_n3},
