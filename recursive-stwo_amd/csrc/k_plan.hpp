@@ -215,10 +215,19 @@ struct PlanArgs {
     uint32_t n;
     PlanPtrs pl;
 };
-template <int BLOCK>
+__device__ void qconst_row_body(uint32_t block, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets, uint32_t n,
+                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs);
+// QCONST (small batches, chain stream layout): the workgroups behind the plan's also compute the query-independent
+// quotient constants in their row form (k_qconst_row's body for qconst_n proofs) — both need only the transcript and
+// both precede k_query on the step's chain of dependent kernels, where a launch of its own costs 12-25 us.
+template <int BLOCK, bool QCONST = false>
 __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                     const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs,
-                                                    Fused<PlanArgs> f) {
+                                                    Fused<PlanArgs> f, uint32_t qconst_n) {
+    if (QCONST && blockIdx.x >= f.first_block[f.nb]) {
+        qconst_row_body(blockIdx.x - f.first_block[f.nb], blob, offsets, qconst_n, metas, ctxs);
+        return;
+    }
     RSV_FUSED_SELECT(f, pa, bx);
     const uint32_t n = pa.n;
     const PlanPtrs& pl = pa.pl;
@@ -515,8 +524,12 @@ static_assert(make_qtab().n[3] <= N_APOW && make_qtab().n[3] == 134 && make_qtab
 __global__ __launch_bounds__(256) void k_qconst_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                     uint32_t n, const ProofMeta* __restrict__ metas,
                                                     ProofCtx* __restrict__ ctxs) {
+    qconst_row_body(blockIdx.x, blob, offsets, n, metas, ctxs);
+}
+__device__ void qconst_row_body(uint32_t block, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets, uint32_t n,
+                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs) {
     const uint32_t i = threadIdx.x & 15u;
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t p = (block * blockDim.x + threadIdx.x) >> 4;
     if (p >= n) return;  // whole rows leave together (DPP needs every lane of a live row)
     const ProofMeta& m = metas[p];
     if (m.reason != R_OK) return;

@@ -63,7 +63,7 @@ __device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, 
         st.s[i] = self_is_right ? sibling.w[i] : self.w[i];
         st.s[8 + i] = self_is_right ? self.w[i] : sibling.w[i];
     }
-    return rate_of(poseidon2(st));
+    return poseidon2_half(st, 0u);
 }
 // combine_hash_tree_with_column (primitives/merkle/src/lib.rs:43-48)
 __device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate(tree, col_cap); }

@@ -284,9 +284,10 @@ __device__ __forceinline__ void partial_round(uint32_t* s, uint32_t k2, uint32_t
     for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
 }
 
-__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
+// Everything up to and including the S-box layer of the last full round: s = that layer's outputs (range L2).
+__device__ __forceinline__ void poseidon2_rounds(uint32_t* s, uint32_t k2, uint32_t k4) {
     uint64_t V[16];
-    const uint32_t k2 = opaque(2), k4 = opaque(4), k6 = opaque(6);
+    const uint32_t k6 = opaque(6);
     // s: canonical input.  V never carries a round constant: the constants are literals of the fused reductions.
     mds16_2x(k2, k4, s, V);
     sbox_full<0, 0>(V, s); mds16_2x(k2, k4, s, V);
@@ -311,12 +312,48 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
     sbox_full4<0>(s);      mds16_2x(k2, k4, s, V);
     sbox_full<5, 0>(V, s); mds16_2x(k2, k4, s, V);
     sbox_full<6, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<7, 0>(V, s); mds16_2x(k2, k4, s, V);
+    sbox_full<7, 0>(V, s);
+}
+
+__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
+    const uint32_t k2 = opaque(2), k4 = opaque(4);
+    poseidon2_rounds(s, k2, k4);
+    uint64_t V[16];
+    mds16_2x(k2, k4, s, V);
     // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         uint32_t t = fold2(V[i]);
         s[i] = min(t, t - P);
+    }
+}
+
+// The last linear layer for ONE half of the state (hi = 0: words 0..7, the rate; 1: words 8..15, the capacity): the four
+// M4 blocks and the column sums are needed either way, the per-word additions, folds and canonicalisations only for
+// the eight words asked for — every hash of the verify pipeline keeps one half of the permutation's output
+// (Poseidon2HalfVar::permute's ignore_left_result / ignore_right_result, primitives/poseidon31/src/lib.rs:251-288).
+__device__ __forceinline__ void poseidon2_inline_half(uint32_t* s, uint32_t hi, uint32_t* out8) {
+    const uint32_t k2 = opaque(2), k4 = opaque(4);
+    poseidon2_rounds(s, k2, k4);
+    uint64_t V[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
+    uint64_t sum[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sum[j] = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+    if (hi) {  // wave-uniform at every call site: a branch, not sixteen selects
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t t = fold2(add64(V[8 + i], sum[i & 3]));
+            out8[i] = min(t, t - P);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t t = fold2(add64(V[i], sum[i & 3]));
+            out8[i] = min(t, t - P);
+        }
     }
 }
 
@@ -329,7 +366,7 @@ __shared__ unsigned s_perm_tag;
 #define RSV_TAG(k) do { } while (0)
 #endif
 
-// Out-of-line instance shared by every call site of the large kernels.
+// Out-of-line instance with the whole output state: rsv_poseidon2_permute*, the PoseidonFlow kernels.
 __device__ __noinline__ State16 poseidon2(State16 st) {
 #ifdef RSV_COUNT_PERMS
     {
@@ -373,8 +410,23 @@ __device__ __forceinline__ Hash8 zero8() {
     for (int i = 0; i < 8; i++) h.w[i] = 0;
     return h;
 }
-__device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return rate_of(poseidon2(join(l, r))); }
-__device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return cap_of(poseidon2(join(l, r))); }
+// Out-of-line instance shared by every hash of the verify kernels: one half of the output (hi = 0 rate, 1 capacity).
+__device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
+#ifdef RSV_COUNT_PERMS
+    {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m));
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
+        }
+    }
+#endif
+    Hash8 h;
+    poseidon2_inline_half(st.s, hi, h.w);
+    return h;
+}
+__device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 0u); }
+__device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 1u); }
 __device__ __forceinline__ bool hash_eq(const Hash8& a, const Hash8& b) {
     uint32_t d = 0;
 #pragma unroll

@@ -506,10 +506,23 @@ def join_variable_part(d) -> bytes:
     return np.concatenate([np.asarray(x, dtype=np.uint32) for x in out]).tobytes()
 
 
+class _Cheap:
+    """copy.deepcopy of a parsed proof costs ~0.2 s for the 80-query shapes (tens of thousands of small arrays) and the
+    mutant generators make ~150 copies per fixture: the lists are copied, the arrays (never modified in place) shared."""
+
+    @staticmethod
+    def deepcopy(d):
+        return {"head": d["head"], "hash_witness": [list(x) for x in d["hash_witness"]],
+                "queried_values": [list(x) for x in d["queried_values"]], "nonce": d["nonce"],
+                "layers": [{"fri_witness": list(l["fri_witness"]), "hash_witness": list(l["hash_witness"]), "commitment": l["commitment"]}
+                           for l in d["layers"]],
+                "last": list(d["last"]), "tail": d["tail"]}
+
+
 def structural_mutants(proof: bytes):
     """Structurally valid re-serializations with one list one element too short / too long, or with elements moved:
     they parse, and must fail in the stage that consumes the list.  Returns [(tag, bytes)]."""
-    import copy
+    copy = _Cheap
     base = split_variable_part(proof)
     out = []
 
@@ -535,7 +548,7 @@ def structural_mutants(proof: bytes):
             d = copy.deepcopy(base); d["layers"][i][key].append(z); emit(f"layer[{i}].{key}+1", d)
     if len(base["layers"]) > 2:
         d = copy.deepcopy(base); d["layers"].pop(); emit("inner layers -1", d)
-        d = copy.deepcopy(base); d["layers"].append(copy.deepcopy(d["layers"][-1])); emit("inner layers +1", d)
+        d = copy.deepcopy(base); d["layers"].append(dict(d["layers"][-1])); emit("inner layers +1", d)
         d = copy.deepcopy(base); d["layers"][1], d["layers"][2] = d["layers"][2], d["layers"][1]; emit("inner layers swapped", d)
     d = copy.deepcopy(base); d["last"].pop(); emit("last-1", d)
     d = copy.deepcopy(base); d["last"].append(zero4); emit("last+1", d)
@@ -550,7 +563,7 @@ def noncanonical_structural_mutants(proof: bytes):
     verdict is reject either way; the REASON must be PARSE (a non-canonical field element outranks every later
     stage), which the product can only say if its canonicity check reaches words no stage reads (csrc/layout.hpp:
     F_RESCAN).  Returns [(tag, bytes)]."""
-    import copy
+    copy = _Cheap
     base = split_variable_part(proof)
     out = []
     P_, MAXW = 0x7FFFFFFF, 0xFFFFFFFF
