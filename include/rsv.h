@@ -151,8 +151,11 @@ typedef enum rsv_option {
     RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 8), else 1 .. 64 gather threads of rsv_verify_batch_host */
     RSV_OPT_DEBUG_LOG = 12,       /* 0 / 1: print failing HIP calls to stderr (process-wide, ctx ignored) */
     RSV_OPT_CRITICAL_CHAIN = 13,  /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
-    RSV_OPT_DEVICE_ORDER = 14     /* 0 / 1 batches under one configuration: slot order by shape on the device, no host round
+    RSV_OPT_DEVICE_ORDER = 14,    /* 0 / 1 batches under one configuration: slot order by shape on the device, no host round
                                      trip inside the call; 2 the host-side bucketing of multi-configuration batches */
+    RSV_OPT_GRAPH = 15            /* 0 / 2 off; 1 (experiment) a call repeated with identical arguments — same buffers, sizes,
+                                     configuration, public inputs — is captured into a HIP graph on its second sighting
+                                     and replayed afterwards; rsv_last_stage_times then reports the last plain call */
 } rsv_option;
 int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 

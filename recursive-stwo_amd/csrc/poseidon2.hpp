@@ -332,27 +332,32 @@ __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
 // M4 blocks and the column sums are needed either way, the per-word additions, folds and canonicalisations only for
 // the eight words asked for — every hash of the verify pipeline keeps one half of the permutation's output
 // (Poseidon2HalfVar::permute's ignore_left_result / ignore_right_result, primitives/poseidon31/src/lib.rs:251-288).
+template <bool HI_CONST = false, bool HI_VALUE = false>
 __device__ __forceinline__ void poseidon2_inline_half(uint32_t* s, uint32_t hi, uint32_t* out8) {
+    if (HI_CONST) hi = HI_VALUE ? 1u : 0u;
     const uint32_t k2 = opaque(2), k4 = opaque(4);
     poseidon2_rounds(s, k2, k4);
     uint64_t V[16];
 #pragma unroll
     for (int g = 0; g < 4; g++)
         mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
-    uint64_t sum[4];
+    // one column at a time (the column sum lives in two registers), the branch outside the loop: the instance must fit
+    // the 40 caller-saved registers v0..v39 like poseidon2(), or the Merkle kernels spill around every call
+    if (hi) {  // wave-uniform at every call site
 #pragma unroll
-    for (int j = 0; j < 4; j++) sum[j] = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
-    if (hi) {  // wave-uniform at every call site: a branch, not sixteen selects
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t t = fold2(add64(V[8 + i], sum[i & 3]));
-            out8[i] = min(t, t - P);
+        for (int j = 0; j < 4; j++) {
+            const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+            const uint32_t t0 = fold2(add64(V[8 + j], sum)), t1 = fold2(add64(V[12 + j], sum));
+            out8[j] = min(t0, t0 - P);
+            out8[4 + j] = min(t1, t1 - P);
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t t = fold2(add64(V[i], sum[i & 3]));
-            out8[i] = min(t, t - P);
+        for (int j = 0; j < 4; j++) {
+            const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+            const uint32_t t0 = fold2(add64(V[j], sum)), t1 = fold2(add64(V[4 + j], sum));
+            out8[j] = min(t0, t0 - P);
+            out8[4 + j] = min(t1, t1 - P);
         }
     }
 }
@@ -410,6 +415,29 @@ __device__ __forceinline__ Hash8 zero8() {
     for (int i = 0; i < 8; i++) h.w[i] = 0;
     return h;
 }
+#ifndef RSV_HALF_INSTANCES
+#define RSV_HALF_INSTANCES 2   // 1: one out-of-line instance with a run-time half selector (51 VGPRs: the Merkle kernels spill 32 B per lane around the calls); 2: one instance per half (39 VGPRs each, no spill).  Same step time (35.06-35.14 vs 35.10-35.16 ms); 2 moves 1 GB less
+#endif
+#if RSV_HALF_INSTANCES == 2
+template <bool HI>
+__device__ __noinline__ Hash8 poseidon2_half_t(State16 st) {
+#ifdef RSV_COUNT_PERMS
+    {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m));
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
+        }
+    }
+#endif
+    Hash8 h;
+    poseidon2_inline_half<true, HI>(st.s, 0u, h.w);
+    return h;
+}
+__device__ __forceinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {  // hi is a literal at every call site
+    return hi ? poseidon2_half_t<true>(st) : poseidon2_half_t<false>(st);
+}
+#else
 // Out-of-line instance shared by every hash of the verify kernels: one half of the output (hi = 0 rate, 1 capacity).
 __device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
 #ifdef RSV_COUNT_PERMS
@@ -422,9 +450,11 @@ __device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
     }
 #endif
     Hash8 h;
-    poseidon2_inline_half(st.s, hi, h.w);
+    // hi is a constant of the call site, the same on every active lane: held in an SGPR, not in a 41st VGPR
+    poseidon2_inline_half(st.s, (uint32_t)__builtin_amdgcn_readfirstlane((int)hi), h.w);
     return h;
 }
+#endif
 __device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 0u); }
 __device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 1u); }
 __device__ __forceinline__ bool hash_eq(const Hash8& a, const Hash8& b) {

@@ -42,6 +42,7 @@ struct Options {
     int host_threads = 0;      // 0 = min(cores, 8)
     int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
     int device_order = 0;      // 0 / 1 single-configuration batches: slot order on the device, no host round trip; 2 host
+    int graph = 0;             // 0 / 2 off, 1 replay repeated identical calls as a HIP graph (experiment)
 };
 static Options g_default_options;
 static std::mutex g_options_mu;
@@ -63,6 +64,8 @@ void destroy_verify_state(VerifyState*);
 struct HostPipe;                          // pinned staging ring of rsv_verify_batch_host (host_stream.inc)
 void destroy_host_pipe(HostPipe*);
 }  // namespace
+struct GraphCache;                        // RSV_OPT_GRAPH (verify_api.inc)
+static void destroy_graph_cache(GraphCache*);
 
 struct rsv_ctx {
     int device = 0;
@@ -82,6 +85,7 @@ struct rsv_ctx {
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
     HostPipe* host_pipe = nullptr;
+    GraphCache* graphs = nullptr;
     Options opt;
 };
 
@@ -182,6 +186,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->vs) destroy_verify_state(c->vs);
     if (c->host_pipe) destroy_host_pipe(c->host_pipe);
+    if (c->graphs) destroy_graph_cache(c->graphs);
     if (c->ws) (void)hipFree(c->ws);
     if (c->ws_fixed) (void)hipFree(c->ws_fixed);
     if (c->ws_rows) (void)hipFree(c->ws_rows);
@@ -216,6 +221,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_OVERLAP_TREES: return tri(&o.overlap_trees);
         case RSV_OPT_CRITICAL_CHAIN: return tri(&o.critical_chain);
         case RSV_OPT_DEVICE_ORDER: return tri(&o.device_order);
+        case RSV_OPT_GRAPH: return tri(&o.graph);
         case RSV_OPT_WS_BUDGET_MB:
             if (value < 1 || value > (1ll << 20)) return RSV_E_RANGE;
             o.ws_budget_mb = value; return RSV_OK;

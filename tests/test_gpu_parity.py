@@ -1311,3 +1311,36 @@ def test_slot_order_on_the_device_and_on_the_host(rsv, knobs, order):
     oacc, oreason = ob.verify_batch(batch, cfg)
     assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist()
     assert int(acc.sum()) > 400 and acc[-1] == 1 and 1 in reason.tolist() and 2 in reason.tolist()
+
+
+def test_graph_replay_of_repeated_calls(rsv):
+    """RSV_OPT_GRAPH (experiment): a call repeated with identical arguments is captured into a HIP graph on its second
+    sighting and replayed afterwards.  The replay reads the buffers as they are THEN: the blob is tampered in place
+    between calls and the verdicts must follow; a call with other arguments drops the graph."""
+    import torch
+    dev = torch.device("cuda:0")
+    proof = read_proof("recursive_proof_16_15.bin")
+    n = 1500
+    blob, offsets = rsv.pack([proof] * n)
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx = rsv.Context(0)
+    ctx.set_option("graph", "on")
+    cfg = rsv.PreparedCfg([fixture_cfg("recursive_proof_16_15.bin")])
+    want = np.ones(n, np.uint8)
+    for rep in range(6):
+        if rep >= 2:  # tamper one more proof in place: plain call, capture, replays all see the bytes of the moment
+            k = 100 * rep + 7
+            d_blob[int(offsets[k]) + 5000] ^= 1
+            want[k] = 0
+        d_acc.fill_(9)
+        ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=cfg)
+        ctx.synchronize()
+        assert np.array_equal(d_acc.cpu().numpy(), want), rep
+    d_acc2 = torch.zeros(n - 1, dtype=torch.uint8, device=dev)  # other arguments: the cached graph is dropped
+    ctx.verify_batch(d_blob, d_off, n - 1, d_acc2, None, cfg=cfg)
+    ctx.synchronize()
+    assert np.array_equal(d_acc2.cpu().numpy(), want[:n - 1])
+    ctx.close()

@@ -1,7 +1,7 @@
 """gpurun_out/<tag>/ (tools/profile.sh) -> profiles/<tag>_{bench_n1_65536.json, bench_under_rocprof.json,
 kernel_stats_bench65536.csv, pmc_summary.csv} and profiles/pmc_latest.json (what bench.py reads for roofline.traffic:
 keyed by a hash of the kernel sources that were profiled, so a stale profile is never quoted).
-Usage: python tools/pmc_summary.py r2_final"""
+Usage: python tools/pmc_summary.py r3_final"""
 import csv
 import glob
 import json
@@ -21,7 +21,7 @@ def last_dispatch_counters(path):
             name = r["Kernel_Name"]
             if "rsv::" not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "")
+            short = name.split("(")[0].replace("void ", "").replace(", ", " ")  # (no commas inside a CSV field)
             d = per.setdefault(short, {})
             key = (int(r["Dispatch_Id"]), r["Counter_Name"])
             d[key] = d.get(key, 0.0) + float(r["Counter_Value"])
@@ -33,7 +33,7 @@ def last_dispatch_counters(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r2_final"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r3_final"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(src, "bench_n1_65536.json"), os.path.join(dst, f"{tag}_bench_n1_65536.json"))
@@ -43,7 +43,7 @@ def main():
     keep = [rows[0]] + [r for r in rows[1:] if "rsv::" in r[0]]
     with open(os.path.join(dst, f"{tag}_kernel_stats_bench65536.csv"), "w", newline="") as f:
         csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(keep)
-    avg_ms = {r[0].split("(")[0].replace("void ", ""): (int(r[1]), float(r[3]) / 1e6) for r in rows[1:] if "rsv::" in r[0]}
+    avg_ms = {r[0].split("(")[0].replace("void ", "").replace(", ", " "): (int(r[1]), float(r[3]) / 1e6) for r in rows[1:] if "rsv::" in r[0]}
     counters = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
         path = glob.glob(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)[0]
@@ -63,7 +63,7 @@ def main():
         f.write("# wave_*_frac: SQ_WAIT_ANY (parked at s_waitcnt / barrier), SQ_WAIT_INST_ANY (ready but not issued: the VALU is taken by another wave) and SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; they sum to ~1\n")
         f.write("# frac_of_perm_mix_issue_ceiling = SQ_INSTS_VALU x 3.440 cycles-at-2.4-GHz (mean issue cost of the permutation's instruction mix, tools/perm_ceiling.py) / (avg_ms x 1024 SIMDs x 2.4 GHz): meaningful for the permutation-dominated kernels only\n")
         f.write("# counter passes serialize the dispatches: per-kernel counters are those of the kernel running ALONE, avg_ms comes from the (concurrent) kernel-trace pass\n")
-        f.write("# kernels on the side stream (k_row_hash, k_query, k_oods, k_qconst, k_scan) overlap main-stream kernels: their durations and clocks are not isolated\n")
+        f.write("# kernels on the side stream (k_row_hash, k_query, k_oods, k_qconst; round 3: k_pair_merkle for single-group batches) overlap main-stream kernels: their durations and clocks are not isolated\n")
         f.write(",".join(cols) + "\n")
         for k in sorted(avg_ms, key=lambda k: -avg_ms[k][1] * avg_ms[k][0]):
             c = counters.get(k, {})

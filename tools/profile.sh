@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the round's profile artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1100 -- 'bash tools/profile.sh r2_final'
+#   gpurun --timeout 1100 -- 'bash tools/profile.sh r3_final'
 # Outputs under gpurun_out/<tag>/ ; tools/pmc_summary.py turns them into the files committed under profiles/.
 # rocprofv3: the program itself follows `--` (no env/bash hop), --pmc passes are separate runs without trace domains.
 set -e -o pipefail
-TAG=${1:-r2_final}
+TAG=${1:-r3_final}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
