@@ -150,34 +150,36 @@ struct ClassTable {
     uint32_t unparsed_cursor;
 };
 
+constexpr uint32_t CLASSIFY_PER_BLOCK = 1024;  // proofs per workgroup of k_classify
 __global__ __launch_bounds__(256) void k_classify(uint32_t n, const uint32_t* __restrict__ shape, ClassTable* __restrict__ tab,
                                                   uint8_t* __restrict__ cls) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0xFFu;  // unparsed
-    if (p < n && shape[2 * p]) {
-        const unsigned long long k = ((unsigned long long)shape[2 * p] << 32) | shape[2 * p + 1];
-        // open addressing from a hash of the key; the table is all but empty (a handful of shapes per batch)
-        uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 58);
-        c = N_CLASSES - 1;
-        for (uint32_t probe = 0; probe < N_CLASSES - 1; probe++, h = (h + 1) % (N_CLASSES - 1)) {
-            unsigned long long cur = tab->key[h];
-            if (cur == 0) cur = atomicCAS(&tab->key[h], 0ull, k);
-            if (cur == 0 || cur == k) { c = h; break; }
+    // per-class counts go through an LDS histogram: ONE global atomic per class and workgroup (a batch has a handful of
+    // classes, so per-wave atomics all hit the same few addresses: 65 536 proofs took 0.28 ms that way, the row hashes
+    // waiting behind it)
+    __shared__ uint32_t hist[N_CLASSES + 1];
+    if (threadIdx.x <= N_CLASSES) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t p0 = blockIdx.x * CLASSIFY_PER_BLOCK, p1 = umin(n, p0 + CLASSIFY_PER_BLOCK);
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        uint32_t c = 0xFFu;  // unparsed
+        if (shape[2 * p]) {
+            const unsigned long long k = ((unsigned long long)shape[2 * p] << 32) | shape[2 * p + 1];
+            // open addressing from a hash of the key; the table is all but empty (a handful of shapes per batch)
+            uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 58) % (N_CLASSES - 1);
+            c = N_CLASSES - 1;
+            for (uint32_t probe = 0; probe < N_CLASSES - 1; probe++, h = (h + 1) % (N_CLASSES - 1)) {
+                unsigned long long cur = tab->key[h];
+                if (cur == 0) cur = atomicCAS(&tab->key[h], 0ull, k);
+                if (cur == 0 || cur == k) { c = h; break; }
+            }
         }
+        cls[p] = (uint8_t)c;
+        atomicAdd(&hist[c == 0xFFu ? N_CLASSES : c], 1u);
     }
-    if (p < n) cls[p] = (uint8_t)c;
-    // per-class counts, one atomic per class and wave
-    unsigned long long todo = __ballot(p < n);
-    const uint32_t lane = threadIdx.x & 63;
-    while (todo) {
-        const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
-        const uint32_t cc = (uint32_t)__shfl((int)c, (int)lead);
-        const unsigned long long same = __ballot(p < n && c == cc);
-        if (lane == lead) {
-            if (cc == 0xFFu) atomicAdd(&tab->unparsed, (uint32_t)__popcll(same));
-            else atomicAdd(&tab->count[cc], (uint32_t)__popcll(same));
-        }
-        todo &= ~same;
+    __syncthreads();
+    if (threadIdx.x <= N_CLASSES && hist[threadIdx.x]) {
+        if (threadIdx.x == N_CLASSES) atomicAdd(&tab->unparsed, hist[threadIdx.x]);
+        else atomicAdd(&tab->count[threadIdx.x], hist[threadIdx.x]);
     }
 }
 

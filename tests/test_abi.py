@@ -63,3 +63,39 @@ def test_argument_validation(rsv):
     assert rsv.lib.rsv_merkle_hash_node(None, None, None, 0, out.ctypes.data_as(rsv._u32p), 1, 0) == -2
     assert rsv.lib.rsv_transcript(None, 0, out.ctypes.data_as(rsv._u32p), 16, 0) == -1
     assert rsv.lib.rsv_ctx_create(0, None) == -1
+
+
+def test_options_are_explicit_and_validated(rsv):
+    """The library reads no environment variable: every knob goes through rsv_ctx_set_option (ctx = NULL: process
+    default), unknown options and out-of-range values are refused — no device needed for any of this."""
+    lib = rsv.lib
+    assert lib.rsv_ctx_set_option(None, 999, 1) == -2          # RSV_E_SIZE: unknown option
+    assert lib.rsv_ctx_set_option(None, 0, 1) == -2
+    for name in ("transcript_form", "transcript_split", "oods_form", "qconst_form", "plan_form", "tree_cap", "overlap_trees",
+                 "critical_chain", "device_order", "graph"):
+        assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], 3) == -5, name   # RSV_E_RANGE
+        assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], -1) == -5, name
+        for v in (2, 1, 0):
+            assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], v) == 0, name
+    for name, bad, good in (("ws_budget_mb", 0, 8192), ("perm_wg_per_cu", 9, 8), ("host_chunk_mb", 0, 256), ("host_threads", 65, 0),
+                            ("debug_log", 2, 0)):
+        assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], bad) == -5, name
+        assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], good) == 0, name
+    # no getenv anywhere in the product sources, no RSV_ variable in the library's strings
+    import subprocess
+    for root, _, files in os.walk(os.path.join(ROOT, "recursive-stwo_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hpp", ".hip", ".inc")):
+                assert "getenv" not in open(os.path.join(root, f)).read(), f
+    syms = subprocess.run(["nm", "-D", "--undefined-only", rsv.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+
+
+def test_poseidon_flow_count_is_host_arithmetic(rsv):
+    """rsv_poseidon_flow_count needs no device; SURVEY App. C shapes: small_proof 3 481, recursive_proof_16_15 5 289."""
+    from tests.conftest import fixture_cfg
+    assert rsv.poseidon_flow_count(4, 8, fixture_cfg("small_proof.bin")) == 3481
+    assert rsv.poseidon_flow_count(16, 15, fixture_cfg("recursive_proof_16_15.bin")) == 5289
+    assert rsv.poseidon_flow_count(19, 18, fixture_cfg("level1-5.bin")) == 28095
+    with pytest.raises(rsv.RsvError):
+        rsv.poseidon_flow_count(0, 8, fixture_cfg("small_proof.bin"))

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything profiles/r3_* is made from, on the GPU box:  gpurun --timeout 1100 -- 'bash tools/round3_artifacts.sh'
+OUT=gpurun_out/r3_art
+mkdir -p $OUT
+python -m pytest tests -m gpu -x -q --durations=6 > $OUT/tests.log 2>&1; echo "rc=$?" >> $OUT/tests.log; tail -4 $OUT/tests.log
+bash tools/profile.sh r3_final 2>&1 | grep -E "done|Error|error" 
+bash tools/bench_matrix.sh r3_art/matrix > $OUT/bench_matrix.txt 2>&1; cat $OUT/bench_matrix.txt
+bash tools/sweep.sh r3_art/sweep "512 1024 2048 4096 8192 16384 32768 65536" default >> $OUT/bench_matrix.txt 2>&1; tail -8 $OUT/bench_matrix.txt
+timeout -k 10 300 python bench.py --workload copies --proofs 65536 --emit-flow --steps 3 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_flow_65536.json 2> $OUT/flow.err; echo flow done
+timeout -k 10 300 python bench.py --workload copies --proofs 65536 --emit-paths --steps 3 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_all_hints_65536.json 2> $OUT/hints.err; echo hints done
+timeout -k 10 300 python bench.py --proofs 131072 --steps 3 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_131072_config3_shard.json 2> $OUT/shard.err; echo shard done
+timeout -k 10 500 python bench.py --total-proofs 1048576 --steps 1 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_total_1048576_1gpu.json 2> $OUT/total.err; echo total done
+timeout -k 10 300 python tests/perm_census.py > $OUT/perm_census.txt 2>&1; echo census done
+timeout -k 10 300 python tests/soak.py 1500 31 - single 300 > $OUT/soak.txt 2>&1; tail -2 $OUT/soak.txt
+timeout -k 10 300 python tests/soak.py 1500 32 pow0 >> $OUT/soak.txt 2>&1; tail -1 $OUT/soak.txt
+python3 - <<'PY'
+import json
+for f in ("bench_flow_65536","bench_all_hints_65536","bench_131072_config3_shard","bench_total_1048576_1gpu"):
+    try:
+        d=json.load(open("gpurun_out/r3_art/%s.json"%f)); print(f, round(d["value"]), round(d["ms_per_step"],2))
+    except Exception as e: print(f,"FAILED",e)
+PY

@@ -14,6 +14,8 @@ while first > 0 and "k_transcript_row<1>" in rows[first - 1]["Kernel_Name"]:
 t0 = int(rows[first]["Start_Timestamp"])
 prev_end = t0
 for r in rows[first:]:
+    if "k_permute" in r["Kernel_Name"] or "k_emulated" in r["Kernel_Name"]:
+        break  # (the microbenchmarks bench.py runs behind the timed steps)
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rsv::", "")
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     print(f"{name:28s} q{r.get('Queue_Id', '?'):>3s} {s:9.1f} -> {e:9.1f}  ({e - s:8.1f} us)  grid {r.get('Grid_Size', '?')}")
