@@ -35,6 +35,12 @@ int main(int argc, char** argv) {
         // FiatShamirResults -> CompositionCheck -> AnswerResults -> FoldingResults (:48-82)
         Verifier::verify(proof, config, inputs);
         printf("proof accepted\n");
+        // cs.pad(); ...; cs.check_poseidon_invocations() (:85-88), values of the Poseidon accelerator only: the flow the
+        // circuit would have recorded, from the GPU's verifying pass; the reference prints the same two sizes (:46-83)
+        PoseidonFlow flow = PoseidonFlow::compute(proof, config, inputs);
+        flow.check_poseidon_invocations();
+        printf("Poseidon circuit size: %zu invocations -> log_size_poseidon %u of the next level's proof\n", flow.invocations.size(),
+               flow.log_size_poseidon());
     } catch (const VerificationError& e) {
         printf("proof rejected: %s\n", e.what());
         return 1;

@@ -412,7 +412,7 @@ typedef struct {
     uint32_t* d_fri_cols;
     uint32_t* d_fri_folded;
     uint32_t* d_query_values;
-    /* PoseidonFlow (ABI v3), see below */
+    /* PoseidonFlow (ABI v3), see above */
     uint32_t* d_flow;
     uint8_t* d_flow_swap;
     uint32_t* d_flow_count;

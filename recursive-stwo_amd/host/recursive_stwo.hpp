@@ -328,6 +328,86 @@ struct ProofShape {  // read from the proof header
     static uint32_t poseidon_cols(int t) { return t == 0 ? 40u : t == 1 ? 48u : t == 2 ? 8u : 0u; }
 };
 
+// PoseidonFlow (stwo_examples::plonk_with_poseidon::poseidon, used by constraint_system/src/plonk_with_poseidon.rs:13-15,
+// 36,117-128): what the recursion circuit records for its Poseidon accelerator — one (entry_1, entry_2, entry_3,
+// entry_4, swap_option) per Poseidon2HalfVar::permute invocation, in invocation order.  compute() takes the VALUE side
+// from the GPU's verifying pass (rsv_hints_out::d_flow); the wire indices (PoseidonEntry::wire, SwapOption::addr) are
+// circuit bookkeeping of the Rust constraint system and are 0 here.
+struct PoseidonEntry {
+    size_t wire = 0;
+    Hash hash{};
+};
+struct SwapOption {
+    size_t addr = 0;
+    bool swap = false;
+};
+struct PoseidonFlow {
+    struct Invocation { PoseidonEntry entry_1, entry_2, entry_3, entry_4; SwapOption swap_option; };
+    std::vector<Invocation> invocations;  // = PoseidonFlow.0
+
+    // the circuit of examples/multi-proofs/src/main.rs:69-139 for ONE verification of `proof`
+    static PoseidonFlow compute(const std::vector<uint8_t>& proof, const PcsConfig& config, const Inputs& inputs) {
+        const ProofShape sh = ProofShape::of(proof);
+        const rsv_pcs_config abi_cfg = config.abi();
+        uint32_t count = 0;
+        if (rsv_poseidon_flow_count(sh.lp, sh.lq, &abi_cfg, &count) != RSV_OK) throw VerificationError(RSV_R_PARSE);
+        std::vector<uint32_t> rec((size_t)count * 32), got(1);
+        std::vector<uint8_t> swap(count);
+        rsv_hints_out ho{};
+        ho.d_flow = rec.data(); ho.d_flow_swap = swap.data(); ho.d_flow_count = got.data(); ho.flow_stride = count;
+        const uint64_t offsets[2] = {0, proof.size()};
+        uint8_t accept = 0, reason = 0;
+        auto pi = abi_inputs(inputs);
+        const rsv_cfg_set cfg_set{&abi_cfg, 1, nullptr};
+        check(rsv_verify_hints(proof.data(), offsets, 1, &cfg_set, pi.data(), pi.size(), &ho, &accept, &reason, default_device()),
+              "rsv_verify_hints");
+        if (!accept) throw VerificationError((rsv_reason)reason);
+        if (got[0] != count) throw VerificationError(RSV_R_PARSE);
+        PoseidonFlow f;
+        f.invocations.resize(count);
+        for (uint32_t i = 0; i < count; i++) {
+            Invocation& v = f.invocations[i];
+            for (int k = 0; k < 8; k++) {
+                v.entry_1.hash[k] = rec[(size_t)i * 32 + k];
+                v.entry_2.hash[k] = rec[(size_t)i * 32 + 8 + k];
+                v.entry_3.hash[k] = rec[(size_t)i * 32 + 16 + k];
+                v.entry_4.hash[k] = rec[(size_t)i * 32 + 24 + k];
+            }
+            v.swap_option.swap = swap[i] != 0;
+        }
+        return f;
+    }
+    // PlonkWithPoseidonConstraintSystem::check_poseidon_invocations, values half (plonk_with_poseidon.rs:468-519):
+    // permute(swap ? r2 || r1 : r1 || r2) == r3 || r4 for every invocation
+    void check_poseidon_invocations() const {
+        const size_t n = invocations.size();
+        std::vector<uint32_t> l(8 * n), r(8 * n), rate(8 * n), cap(8 * n);
+        std::vector<uint8_t> sw(n);
+        for (size_t i = 0; i < n; i++) {
+            for (int k = 0; k < 8; k++) { l[8 * i + k] = invocations[i].entry_1.hash[k]; r[8 * i + k] = invocations[i].entry_2.hash[k]; }
+            sw[i] = invocations[i].swap_option.swap ? 1 : 0;
+        }
+        check(rsv_poseidon2_half_permute(l.data(), r.data(), sw.data(), rate.data(), cap.data(), n, default_device()),
+              "rsv_poseidon2_half_permute");
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 8; k++)
+                if (rate[8 * i + k] != invocations[i].entry_3.hash[k] || cap[8 * i + k] != invocations[i].entry_4.hash[k])
+                    throw VerificationError(RSV_R_PARSE);
+    }
+    // log size of the Poseidon component a circuit with `multipliers` such verifications is proved with: the flow is
+    // padded to a multiple of 16, at least 32 (PlonkWithPoseidonConstraintSystem::pad, plonk_with_poseidon.rs:282-318),
+    // six trace rows per invocation (components/recursive/composition/src/poseidon.rs: first / full / full / partial /
+    // full / full), next power of two.  This is the second header word of the next level's proof.
+    uint32_t log_size_poseidon(size_t multipliers = 1) const {
+        size_t len = invocations.size() * multipliers;
+        size_t padded = (len + 15) / 16 * 16;
+        if (padded < 32) padded = 32;
+        uint32_t lg = 0;
+        while (((size_t)1 << lg) < 6 * padded) lg++;
+        return lg;
+    }
+};
+
 struct Hints {
     // FiatShamirHints (values), DecommitHints, FirstLayerHints, InnerLayersHints of one proof
     FiatShamirResults fiat_shamir;

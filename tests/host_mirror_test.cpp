@@ -4,6 +4,7 @@
 //   test_consistency (merkle)   primitives/merkle/src/lib.rs:206-303 (expected values: SURVEY App. C)
 //   test_fiat_shamir            components/recursive/fiat_shamir/src/lib.rs:197-236 (challenges: SURVEY App. C)
 //   test_folding (= full verify) components/recursive/folding/src/lib.rs:231-303
+//   test_poseidon_flow          constraint_system/src/plonk_with_poseidon.rs:282-318,468-519 on the GPU-recorded flow
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -173,6 +174,32 @@ static void test_hints(const std::vector<uint8_t>& small) {
     EXPECT(threw);
 }
 
+// constraint_system/src/plonk_with_poseidon.rs:468-519 (check_poseidon_invocations) + :282-318 (pad) on the flow the
+// GPU's verifying pass records: every invocation permutes to its outputs, the transcript part is the channel chain, and
+// the padded flow of small_proof.bin's verification is the 2^15-row Poseidon component of recursive_proof_16_15.bin
+// (examples/single-proof/src/main.rs:100-103), that proof's verified 5 times level1-5.bin's 2^18 rows
+// (examples/multi-proofs/src/main.rs:198-204).
+static void test_poseidon_flow(const std::vector<uint8_t>& small, const std::vector<uint8_t>& rec, const std::vector<uint8_t>& level1) {
+    PoseidonFlow f = PoseidonFlow::compute(small, PcsConfig{20, FriConfig::make(2, 5, 16)}, {{1, QM31{1, 0, 0, 0}}});
+    EXPECT(f.invocations.size() == 3481);
+    f.check_poseidon_invocations();
+    // mix_root(commitment 0) on the zero digest, then mix_one_felt(log_size_plonk) on its capacity
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(small.data());
+    for (int k = 0; k < 8; k++) EXPECT(f.invocations[0].entry_1.hash[k] == w[17 + k] && f.invocations[0].entry_2.hash[k] == 0);
+    EXPECT(f.invocations[1].entry_2.hash == f.invocations[0].entry_4.hash && f.invocations[1].entry_1.hash[0] == w[0]);
+    EXPECT(f.log_size_poseidon() == reinterpret_cast<const uint32_t*>(rec.data())[1] && f.log_size_poseidon() == 15);
+    Inputs std_inputs = {{1, QM31{1, 0, 0, 0}}, {2, QM31{0, 1, 0, 0}}, {3, QM31{0, 0, 1, 0}}};
+    PoseidonFlow g = PoseidonFlow::compute(rec, PcsConfig{20, FriConfig::make(8, 5, 16)}, std_inputs);
+    EXPECT(g.invocations.size() == 5289);
+    g.check_poseidon_invocations();
+    EXPECT(g.log_size_poseidon(5) == reinterpret_cast<const uint32_t*>(level1.data())[1] && g.log_size_poseidon(5) == 18);
+    // a flipped output word is caught
+    g.invocations[1234].entry_3.hash[3] ^= 1;
+    bool threw = false;
+    try { g.check_poseidon_invocations(); } catch (const VerificationError&) { threw = true; }
+    EXPECT(threw);
+}
+
 int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "tests/golden/proofs";
     auto small = read_file(dir + "/small_proof.bin");
@@ -183,6 +210,7 @@ int main(int argc, char** argv) {
     test_fiat_shamir(small);
     test_verify(small);
     test_hints(small);
+    test_poseidon_flow(small, read_file(dir + "/recursive_proof_16_15.bin"), read_file(dir + "/level1-5.bin"));
     printf("host mirror: all tests passed\n");
     return 0;
 }

@@ -47,6 +47,9 @@ def test_examples_run(tmp_path):
     out = subprocess.run([_build_example(tmp_path, "single_proof"), os.path.join(proofs, "small_proof.bin")],
                          capture_output=True, text=True)
     assert out.returncode == 0 and "proof accepted" in out.stdout and "192 per-query Merkle paths" in out.stdout, out.stdout + out.stderr
+    # the recursion circuit of examples/single-proof verifies small_proof.bin once: 3 481 Poseidon invocations, which pad
+    # to the 2^15 Poseidon rows in the header of the proof it writes (recursive_proof_16_15.bin)
+    assert "3481 invocations -> log_size_poseidon 15" in out.stdout, out.stdout
     files = [os.path.join(proofs, f) for f in ("level1-5.bin", "level7-1.bin", "level13-1.bin", "hybrid_hash.bin")]
     out = subprocess.run([_build_example(tmp_path, "multi_proofs")] + files, capture_output=True, text=True)
     lines = out.stdout.strip().splitlines()
