@@ -10,15 +10,19 @@ namespace rsv {
 // FLOW: also writes the PoseidonFlow records of the channel operations (layout.hpp; rsv_hints_out::d_flow), including
 // the surplus query draws the circuit makes (it draws ceil(n_queries / 4) times where ceil(n_queries / 8) hold every
 // query, fiat_shamir/src/lib.rs:119-130), and decides whether this proof's records fit the caller's stride.
-template <bool FLOW>
+template <bool FLOW, int PHASE = 0>
 __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                    uint32_t n, const ProofMeta* __restrict__ metas,
                                                    ProofCtx* __restrict__ ctxs, FlowArgs fa) {
+    static_assert(!FLOW || PHASE == 0, "the PoseidonFlow records are written by the unsplit kernel");
     RSV_TAG(1);
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const ProofMeta& m = metas[p];
-    if (m.reason != R_OK) return;
+    if (PHASE == 1) {  // next to the parser, as k_transcript_row<1> below: its first checks, enough to read the fixed-offset part
+        const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+        if (o1 < o0 || ((o0 | o1) & 3) || (o1 - o0) > (1ull << 30) || ((o1 - o0) >> 2) < SAMPLES.end + 8) return;
+    } else if (m.reason != R_OK) return;
     ProofCtx& c = ctxs[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     Channel ch;
@@ -38,9 +42,10 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
         over |= (v.a.a >= P) | (v.a.b >= P) | (v.b.a >= P) | (v.b.b >= P);
         return v;
     };
+    if (PHASE != 2) {
     ch.mix(load_hash_chk(w + W_COMMIT0, over));
-    ch.mix_one(q_from_m(m.lp));  // statement 0: data_structures/src/lib.rs:52-55
-    ch.mix_one(q_from_m(m.lq));
+    ch.mix_one(q_from_m(w[W_LP]));  // statement 0: data_structures/src/lib.rs:52-55 (== m.lp, m.lq once the parser has run)
+    ch.mix_one(q_from_m(w[W_LQ]));
     ch.mix(load_hash_chk(w + W_COMMIT0 + 8, over));
     d = ch.draw();  // lookup elements z, alpha: data_structures/src/lib.rs:242-245
     stq(c.z, q_lo(d)); stq(c.alpha, q_hi(d));
@@ -63,6 +68,16 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
         ch.mix_two(ldq_chk(w + SAMPLES.off[k]), ldq_chk(w + SAMPLES.off[k + 1]));
     d = ch.draw();
     stq(c.after, q_lo(d));
+    if (PHASE == 1) {  // hand the digest (and what the canonicity check found) to the back half
+        store_hash(c.pow_digest, ch.digest);
+        c.front_over = over;
+        return;
+    }
+    }  // PHASE != 2
+    if (PHASE == 2) {
+        ch.digest = load_hash(c.pow_digest);
+        over = c.front_over;
+    }
     ch.mix(load_hash_chk(w + m.first.commit_off, over));
     d = ch.draw();
     stq(c.fri_alpha[0], q_lo(d));

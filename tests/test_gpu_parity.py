@@ -587,12 +587,14 @@ def test_canonicity_is_checked_where_words_are_read(rsv):
         assert (int(a1[0]), int(r1[0])) == (int(oa), int(orr))
 
 
+@pytest.mark.parametrize("form", ["row", "lane"])
 @pytest.mark.parametrize("split", ["whole", "split"])
-def test_row_transcript_in_one_piece_and_split(rsv, knobs, split):
-    """The row-form transcript as one launch and as front (next to the parser, before any section offset is known) +
+def test_transcript_in_one_piece_and_split(rsv, knobs, split, form):
+    """Either transcript form as one launch and as front (next to the parser, before any section offset is known) +
     back: the same verdicts, reasons and transcript rows, also for buffers the front half has to leave alone
-    (empty, truncated inside the fixed-offset part, cut right behind it, misaligned length)."""
-    knobs.set("transcript_form", "row")
+    (empty, truncated inside the fixed-offset part, cut right behind it, misaligned length), and a non-canonical word
+    in the front's part of the proof, whose finding travels to the back half."""
+    knobs.set("transcript_form", form)
     knobs.set("transcript_split", split)
     proof = read_proof("recursive_proof_16_15.bin")
     cfg = fixture_cfg("recursive_proof_16_15.bin")
@@ -606,6 +608,15 @@ def test_row_transcript_in_one_piece_and_split(rsv, knobs, split):
     rows = rsv.transcript_batch(batch, cfgs)
     for k in (0, 9, 10):
         assert np.array_equal(rows[k], _row_from_raw(ob.transcript_raw(batch[k])))
+    words = np.frombuffer(proof, np.uint32)
+    over = []
+    for spot in (3, 20, 56, 894):  # a claimed sum, a commitment word, sampled values: all absorbed by the front half
+        w = words.copy()
+        w[spot] = 0x80000001
+        over.append(w.tobytes())
+    acc, reason = rsv.verify_batch(over + [proof], cfg)
+    oacc, oreason = ob.verify_batch(over + [proof], cfg)
+    assert acc.tolist() == oacc.tolist() == [0, 0, 0, 0, 1] and reason.tolist() == oreason.tolist() == [1, 1, 1, 1, 0]
 
 
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level13-1.bin"])
