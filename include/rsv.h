@@ -437,6 +437,46 @@ int rsv_poseidon_flow_count(uint32_t log_size_plonk, uint32_t log_size_poseidon,
 int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg, uint32_t* out,
                          int device);
 
+/* ---- SURVEY 8f.1, completed: the recursion circuit's witness ------------------------------------------------------
+ * What the reference's circuit leaves for the next prover is `variables: Vec<QM31>`
+ * (constraint_system/src/plonk_with_poseidon.rs:19): one value per cs.add / cs.mul / cs.mul_constant / new_m31 /
+ * new_qm31 call of the gadgets, in call order (:140-283); the trace columns a_val / b_val / c_val are that vector read
+ * through the wires (:571-618).  The reference computes it by running the gadgets on one proof at a time on the CPU.
+ * Which gate or hint produces variable k is the same for every proof of one shape (statement sizes + PcsConfig), so
+ * here the gadgets are run once per shape on the host (recursive-stwo_amd/circuit/: a mirror of the reference's
+ * ConstraintSystemRef / M31Var / ... / FiatShamirResults / CompositionCheck / AnswerResults / FoldingResults that writes
+ * down what it did) and the resulting PROGRAM — one instruction per variable, sorted by dependency depth — is evaluated
+ * on the GPU for a whole batch, from the hints of the verifying pass (proof words, PoseidonFlow records, per-query
+ * column values).  The circuit is `copies` copies of the verifier in one constraint system, as
+ * examples/multi-proofs/src/main.rs:66-139 builds it (`multipliers`); every copy verifies the same proof.
+ *
+ * Instruction = 8 u32: op, dst, a, b, imm0..imm3 (ops: recursive-stwo_amd/csrc/k_witness.hpp WitnessOp; the table with
+ * their meaning heads recursive-stwo_amd/circuit/program.py).  rsv_witness_program_create checks every index the device
+ * will use (RSV_E_RANGE otherwise) and keeps a copy in HBM. */
+typedef struct rsv_witness_program rsv_witness_program;
+typedef struct {
+    uint32_t log_size_plonk, log_size_poseidon;            /* the statement of the proofs the program applies to */
+    uint32_t pow_bits, log_blowup, log_last, n_queries;    /* their PcsConfig */
+    uint32_t n_inner;                                      /* FRI inner layers */
+    uint32_t flow_count;                                   /* rsv_poseidon_flow_count of the shape */
+    uint32_t copies;                                       /* copies of the verifier in the circuit */
+} rsv_witness_shape;
+int rsv_witness_program_create(const uint32_t* instr, size_t n_instr, const uint32_t* level_offsets, size_t n_levels,
+                               uint32_t n_vars, const rsv_witness_shape* shape, int device, rsv_witness_program** out);
+void rsv_witness_program_destroy(rsv_witness_program* prog);
+/* HBM the context will hold for a batch of n proofs (hints of the verifying pass + variables[var][proof]). */
+int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t* bytes);
+/* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and
+ * writes d_variables [n][n_vars][4]: row i = the `variables` vector of the circuit that verifies proof i.
+ * d_accept[i] = 1 iff proof i verified AND is of the program's shape; only those rows are defined (the others hold the
+ * constants and zeros).  d_variables 16-byte aligned. */
+int rsv_witness_eval_dev(rsv_ctx* ctx, const rsv_witness_program* prog, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
+                         const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t* d_variables, uint8_t* d_accept,
+                         uint8_t* d_reason);
+/* Same on host buffers. */
+int rsv_witness_eval(const rsv_witness_program* prog, const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
+                     const rsv_public_input* pi, size_t n_pi, uint32_t* variables, uint8_t* accept, uint8_t* reason, int device);
+
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).
  * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */

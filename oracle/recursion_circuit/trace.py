@@ -10,8 +10,10 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import gadgets as G
-from .cs import P
+
+from . import circuit
+G = circuit.gadgets
+P = circuit.cs.P
 
 PREPROCESSED = ("a_wire", "b_wire", "c_wire", "op", "mult_a", "mult_b", "mult_c", "poseidon_wire", "mult_poseidon", "enforce_c_m31")
 
@@ -110,7 +112,7 @@ class PointEvaluator:
     of all rows are computed once (f(point) = sum_i w_i v_i), so a column costs one dot product."""
 
     def __init__(self, log_size, point):
-        from . import cs as C
+        C = circuit.cs
         n = log_size
         half = G.canonic_half_coset(n)
         hx, hy = _coset_points(half.initial_index, half.step_size, n - 1)
@@ -161,3 +163,95 @@ class PointEvaluator:
         """column: M31 values at the bit-reversed positions, length 2^log_size."""
         col = np.array(column, dtype=object)
         return tuple(int((self.weights[k] * col).sum() % P) for k in range(4))
+
+
+# ---------------------------------------------------------------- the Poseidon component's columns
+# The component's trace generator lives in the un-vendored stwo fork; what follows is what the AIR the verifier
+# evaluates (components/recursive/composition/src/poseidon.rs:73-241) forces, row by row: six rows per invocation —
+# [0] is_first: in = the two input halves as given, intermediate[0] = the swap bit, out = external matrix of the
+# (swapped) input; [1], [2] is_full: two full rounds each, intermediate = the first S-box layer; [3] partial: the 14
+# partial rounds, intermediate[r] = the r-th S-box output; [4], [5] is_full, [5] is_last.  Rows hand their state on
+# through the lookup ids 2 * round_id (+ 0..3), so round_id counts the rounds of the whole flow (6 k + j).
+# What the AIR does not say was found against the fixtures (tests/test_recursion_circuit.py): sixteen invocations share
+# a block of 96 rows, round-major (row = ((k / 16) * 6 + j) * 16 + k % 16 — the SIMD backend's 16 lanes), the words the
+# AIR leaves free are zero, and the rows behind the padded flow have is_first_round = is_last_round = 1.
+def _mds4(x):
+    t0, t1 = x[0] + x[1], x[2] + x[3]
+    t2, t3 = 2 * x[1] + t1, 2 * x[3] + t0
+    t4, t5 = 4 * t1 + t3, 4 * t0 + t2
+    return [(t3 + t5) % P, t5 % P, (t2 + t4) % P, t4 % P]
+
+
+def _ext(s):
+    s = [v for g in range(4) for v in _mds4(s[4 * g:4 * g + 4])]
+    sums = [(s[j] + s[j + 4] + s[j + 8] + s[j + 12]) % P for j in range(4)]
+    return [(s[i] + sums[i % 4]) % P for i in range(16)]
+
+
+def _pow5(x):
+    x2 = x * x % P
+    return x2 * x2 % P * x % P
+
+
+def poseidon_columns(flow, round_constants, log_size, padding_hash=None):
+    """flow: cs.flow after pad(); round_constants: (first[4][16], partial[14], last[4][16]).
+    -> (preprocessed int64[40, n], trace int64[48, n]), n = 2^log_size, rows beyond 6 * len(flow) zero."""
+    first, partial, last = round_constants
+    n = 1 << log_size
+    pre = np.zeros((40, n), dtype=object)
+    tr = np.zeros((48, n), dtype=object)
+    for k, (e1, e2, e3, e4, addr, swap) in enumerate(flow):
+        h1 = list(e1[1]) if e1[1] is not None else list(padding_hash[0])
+        h2 = list(e2[1]) if e2[1] is not None else list(padding_hash[0])
+        rid = 6 * k
+        row = [((k // 16) * 6 + j) * 16 + k % 16 for j in range(6)]
+        rows_in, rows_mid, rows_out = [], [], []
+        state = h1 + h2
+        sw = (h2 + h1) if swap else (h1 + h2)
+        out = _ext(sw)
+        rows_in.append(state); rows_mid.append([1 if swap else 0] + [0] * 15); rows_out.append(out)
+        cur = out
+        for pair in (first[0:2], first[2:4]):
+            mid = [_pow5((cur[i] + pair[0][i]) % P) for i in range(16)]
+            o = _ext([_pow5((v + pair[1][i]) % P) for i, v in enumerate(_ext(mid))])
+            rows_in.append(cur); rows_mid.append(mid); rows_out.append(o)
+            cur = o
+        s = list(cur)
+        mids = []
+        for rr in range(14):
+            s[0] = _pow5((s[0] + partial[rr]) % P)
+            mids.append(s[0])
+            total = sum(s) % P
+            s = [(total + 3 * s[0]) % P] + [(total + (s[i] << (i + 1))) % P for i in range(1, 16)]
+        rows_in.append(cur); rows_mid.append(mids + [0, 0]); rows_out.append(s)
+        cur = s
+        for pair in (last[0:2], last[2:4]):
+            mid = [_pow5((cur[i] + pair[0][i]) % P) for i in range(16)]
+            o = _ext([_pow5((v + pair[1][i]) % P) for i, v in enumerate(_ext(mid))])
+            rows_in.append(cur); rows_mid.append(mid); rows_out.append(o)
+            cur = o
+        if e3[1] is not None:
+            assert cur == list(e3[1]) + list(e4[1])
+        for j in range(6):
+            tr[0:16, row[j]] = rows_in[j]
+            tr[16:32, row[j]] = rows_mid[j]
+            tr[32:48, row[j]] = rows_out[j]
+            pre[3, row[j]] = rid + j
+        pre[0, row[0]] = 1
+        pre[1, row[5]] = 1
+        for j in (1, 2, 4, 5):
+            pre[2, row[j]] = 1
+        pre[4, row[0]] = addr  # rc0[0] of the first row carries the swap bit's address
+        for j, pair in ((1, first[0:2]), (2, first[2:4]), (4, last[0:2]), (5, last[2:4])):
+            pre[4:20, row[j]] = pair[0]
+            pre[20:36, row[j]] = pair[1]
+        pre[4:18, row[3]] = partial
+        pre[36, row[0]], pre[37, row[0]] = e1[0], e2[0]
+        pre[38, row[0]], pre[39, row[0]] = int(e1[0] != 0), int(e2[0] != 0)
+        pre[36, row[5]], pre[37, row[5]] = e3[0], e4[0]
+        pre[38, row[5]], pre[39, row[5]] = int(e3[0] != 0), int(e4[0] != 0)
+    # rows behind the last invocation: a round that is first and last at once over an all-zero state (every constraint
+    # holds, no lookup is made)
+    pre[0, 6 * len(flow):] = 1
+    pre[1, 6 * len(flow):] = 1
+    return pre, tr

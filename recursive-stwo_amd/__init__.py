@@ -123,6 +123,11 @@ class HintsOut(ctypes.Structure):  # rsv_hints_out
                 ("flow_stride", ctypes.c_uint32), ("d_accept_bitmap", ctypes.c_void_p), ("d_accept_count", ctypes.c_void_p)]
 
 
+class WitnessShape(ctypes.Structure):  # rsv_witness_shape
+    _fields_ = [(k, ctypes.c_uint32) for k in ("log_size_plonk", "log_size_poseidon", "pow_bits", "log_blowup", "log_last", "n_queries",
+                                               "n_inner", "flow_count", "copies")]
+
+
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
 
 
@@ -185,6 +190,13 @@ def _load() -> ctypes.CDLL:
                                            ctypes.c_uint32, _u32p, _u32p, _u8p, _u8p, ctypes.c_int]),
         "rsv_last_stage_times": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                                 ctypes.c_int]),
+        "rsv_witness_program_create": (ctypes.c_int, [_u32p, sz, _u32p, sz, ctypes.c_uint32, ctypes.POINTER(WitnessShape), ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_void_p)]),
+        "rsv_witness_program_destroy": (None, [vp]),
+        "rsv_witness_scratch_bytes": (ctypes.c_int, [vp, sz, ctypes.POINTER(sz)]),
+        "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp]),
+        "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u8p, _u8p,
+                                            ctypes.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what rsv.h declares
@@ -201,7 +213,8 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_verify_batch_dev", "rsv_accept_bitmap_dev", "rsv_last_stage_times", "rsv_trace_paths_dev",
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
            "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
-           "rsv_transcript_batch", "rsv_poseidon_flow_count"]
+           "rsv_transcript_batch", "rsv_poseidon_flow_count", "rsv_witness_program_create", "rsv_witness_program_destroy",
+           "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -485,6 +498,76 @@ def poseidon_flow(proofs: Sequence[bytes], cfg, flow_stride: int, inputs=STANDAR
     return flow, swap, count, accept, reason
 
 
+def hints(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: int, flow_stride: int, inputs=STANDARD_INPUTS, device: int = 0):
+    """Everything the reference's hint structs hold for a uniform batch, from one verifying pass (rsv_verify_hints on host
+    buffers): dict of trace_sib, trace_pos, trace_cols, fri_sib, fri_cols, flow, flow_swap, accept, reason (layouts: rsv.h)."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    out = {"trace_sib": np.zeros((n, 4, n_queries, max_log, 8), np.uint32), "trace_pos": np.zeros((n, 4, n_queries), np.uint32),
+           "trace_cols": np.zeros((n, 4, n_queries, 64), np.uint32), "fri_sib": np.zeros((n, 1 + n_inner, n_queries, max_log, 8), np.uint32),
+           "fri_cols": np.zeros((n, 1 + n_inner, n_queries, 3, 8), np.uint32), "flow": np.zeros((n, flow_stride, 32), np.uint32),
+           "flow_swap": np.zeros((n, flow_stride), np.uint8), "accept": np.zeros(n, np.uint8), "reason": np.zeros(n, np.uint8)}
+    pi = make_inputs(inputs)
+    ho = HintsOut(n_queries, max_log, n_inner, None, out["trace_sib"].ctypes.data, out["trace_pos"].ctypes.data, out["trace_cols"].ctypes.data,
+                  out["fri_sib"].ctypes.data, out["fri_cols"].ctypes.data, None, None, out["flow"].ctypes.data, out["flow_swap"].ctypes.data,
+                  None, flow_stride, None, None)
+    _check(lib.rsv_verify_hints(blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(cfg, n).ref(), pi, len(list(inputs)),
+                                ctypes.byref(ho), out["accept"].ctypes.data_as(_u8p), out["reason"].ctypes.data_as(_u8p), device), "rsv_verify_hints")
+    return out
+
+
+class WitnessProgram:
+    """A witness program resident on the device (rsv_witness_program): build one per proof shape with
+    circuit.build_program (or load a saved circuit.program.Program) and evaluate it for batches of that shape."""
+
+    def __init__(self, program, device: int = 0):
+        self.program = program
+        self.n_vars = program.n_vars
+        sh = program.shape
+        self.shape = WitnessShape(sh["lp"], sh["lq"], sh["pow_bits"], sh["blowup"], sh["log_last"], sh["nq"], sh["n_inner"], sh["flow_count"],
+                                  sh["copies"])
+        instr = np.ascontiguousarray(program.instr, dtype=np.uint32)
+        levels = np.ascontiguousarray(program.level_offsets, dtype=np.uint32)
+        h = ctypes.c_void_p()
+        _check(lib.rsv_witness_program_create(instr.ctypes.data_as(_u32p), instr.shape[0], levels.ctypes.data_as(_u32p), len(levels) - 1,
+                                              program.n_vars, ctypes.byref(self.shape), device, ctypes.byref(h)), "rsv_witness_program_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rsv_witness_program_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cfg(self) -> PcsConfig:
+        s = self.shape
+        return PcsConfig(s.pow_bits, s.log_blowup, s.log_last, s.n_queries)
+
+    def scratch_bytes(self, n: int) -> int:
+        out = ctypes.c_size_t(0)
+        _check(lib.rsv_witness_scratch_bytes(self._h, n, ctypes.byref(out)), "rsv_witness_scratch_bytes")
+        return int(out.value)
+
+
+def witness(proofs: Sequence[bytes], program: WitnessProgram, inputs=STANDARD_INPUTS, device: int = 0):
+    """`variables` of the recursion circuit for every proof of a batch (rsv_witness_eval): uint32[n, n_vars, 4], accept, reason."""
+    blob, offsets = pack(proofs)
+    n = len(proofs)
+    variables = np.zeros((n, program.n_vars, 4), np.uint32)
+    accept = np.zeros(n, np.uint8)
+    reason = np.zeros(n, np.uint8)
+    pi = make_inputs(inputs)
+    _check(lib.rsv_witness_eval(program._h, blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(program.cfg(), n).ref(), pi,
+                                len(list(inputs)), variables.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device),
+           "rsv_witness_eval")
+    return variables, accept, reason
+
+
 def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
     """per-query pair paths of the FRI trees.  Returns (sib uint32[n,1+n_inner,nq,max_log,8],
     cols uint32[n,1+n_inner,nq,3,8], accept, reason)."""
@@ -642,6 +725,16 @@ class Context:
         _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")
 
+    def witness(self, program: WitnessProgram, d_blob, d_offsets, n: int, d_variables, d_accept, d_reason=None, inputs=STANDARD_INPUTS):
+        """rsv_witness_eval_dev: d_variables uint32[n, n_vars, 4] in HBM; enqueued on the context's streams."""
+        pi = make_inputs(inputs)
+        pc = self.prepare_cfg(program.cfg(), n)
+        self.acquire_from_torch()
+        self._keep(pc, None)
+        _check(lib.rsv_witness_eval_dev(self._h, program._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
+                                        d_variables.data_ptr(), d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
+               "rsv_witness_eval_dev")
+
     def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):
         self.acquire_from_torch()
         _check(lib.rsv_accept_bitmap_dev(self._h, d_accept.data_ptr(), n, d_bitmap.data_ptr(),
@@ -654,3 +747,6 @@ class Context:
         if k < 0:
             raise RsvError(k, "rsv_last_stage_times")
         return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+
+from . import circuit  # noqa: E402,F401  (host side of rsv_witness_eval_dev: the recursion circuit -> witness program)

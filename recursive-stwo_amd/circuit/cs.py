@@ -1,12 +1,12 @@
-"""TEST INFRASTRUCTURE (oracle): the reference's Plonk-with-Poseidon constraint system and its field variables, restated.
+"""The reference's Plonk-with-Poseidon constraint system and its field variables, mirrored (host side of the witness program).
 
 What the reference's recursion circuit leaves behind for the next prover is `variables: Vec<QM31>` plus the gate lists
 (`a_wire / b_wire / c_wire / op / poseidon_wire / enforce_c_m31`) and the PoseidonFlow
 (constraint_system/src/plonk_with_poseidon.rs:17-41).  Every gadget call appends to them in program order, so the
-vector is only reproduced by replaying the gadgets in that order; this package does that with plain Python integers.
+vector is only reproduced by replaying the gadgets in that order; this module does that with plain Python integers, once
+per proof shape, and keeps for every variable HOW it came to be (`origin`) — the witness program (program.py).
 
 Values: M31 = int, CM31 = (re, im), QM31 = (a0, a1, a2, a3) = (a0 + a1 i) + (a2 + a3 i) j, i^2 = -1, j^2 = 2 + i.
-Only tests/ (and the parity tooling beside them) import this package; the product never does.
 """
 from __future__ import annotations
 
@@ -105,7 +105,7 @@ class ConstraintSystem:
         self.poseidon_wire, self.enforce_c_m31, self.op = [0] * 4, [0] * 4, [1] * 4
         self.flow = []  # (wire1, hash1, wire2, hash2, wire3, hash3, wire4, hash4, swap_addr, swap)
         self.num_input = 3
-        self.hint_tag = None  # the gadget allocating a witness says what it is (hints.py resolves the tags on the GPU side)
+        self.hint_tag = None  # the gadget allocating a witness says what it is (program.py turns the tags into instructions)
 
     # -- rows
     def _row(self, a, b, c, op, pw=0, m31=0):
@@ -140,9 +140,11 @@ class ConstraintSystem:
         self._row(a, b, c, 0, pw=c)
         return c
 
-    def mul_constant(self, a, k):
+    def mul_constant(self, a, k, program_k=None):
+        """program_k: the constant the witness program uses where the reference's gate constant follows the witness
+        (gadgets.pm_select) — same value for every proof, same product for the proof at hand."""
         k %= P
-        c = self._push(q_scale(self.variables[a], k), ("mulc", a, k))
+        c = self._push(q_scale(self.variables[a], k), ("mulc", a, k if program_k is None else program_k % P))
         self.insert_gate(a, 0, c, k)
         return c
 

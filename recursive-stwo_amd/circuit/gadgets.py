@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE (oracle): the reference's circuit gadgets over cs.py, restated in allocation order.
+"""The reference's circuit gadgets over cs.py, mirrored in allocation order.
 
 bits (primitives/bits/src/lib.rs), Poseidon2HalfVar (primitives/poseidon31/src/lib.rs), ChannelVar
 (primitives/channel/src/lib.rs), Poseidon31MerkleHasherVar (primitives/merkle/src/lib.rs), circle points
@@ -132,7 +132,7 @@ def bits_from_m31(v: Var, l: int) -> Bits:
 
 
 # ---------------------------------------------------------------- Poseidon2HalfVar (native form)
-PERMUTE = None  # set by the caller: 16 ints -> 16 ints (the Poseidon2 permutation; oracle/rsv_oracle.c has it)
+PERMUTE = None  # set by the caller: 16 ints -> 16 ints, the Poseidon2 permutation of the state the circuit is about to permute
 
 
 class Half:
@@ -347,9 +347,9 @@ def pm_select(cs, point, bit_value, bit_variable) -> PointM31:
     # the gate constants are taken from the SELECTED value (circle/src/lib.rs:83-98), so this gate's `op` follows the
     # witness bit: 0 when the bit is 0, the step's coordinate when it is 1
     value = point if bit_value else (1, 0)
-    new_x = cs.mul_constant(bit_variable, (value[0] - 1) % P)
+    new_x = cs.mul_constant(bit_variable, (value[0] - 1) % P, program_k=(point[0] - 1) % P)
     new_x = cs.add(new_x, 1)
-    new_y = cs.mul_constant(bit_variable, value[1])
+    new_y = cs.mul_constant(bit_variable, value[1], program_k=point[1])
     return PointM31(Var(cs, value[0], new_x, 1), Var(cs, value[1], new_y, 1))
 
 
@@ -369,8 +369,8 @@ class PointQM31:
         self.x, self.y = x, y
 
 
-def pq_witness(cs, p, tag=None):
-    return PointQM31(C.qm31_witness(cs, p[0], tag and tag + ("x",)), C.qm31_witness(cs, p[1], tag and tag + ("y",)))
+def pq_witness(cs, p, tag_x=None, tag_y=None):
+    return PointQM31(C.qm31_witness(cs, p[0], tag_x), C.qm31_witness(cs, p[1], tag_y))
 
 
 def pq_from_t(t: Var) -> PointQM31:

@@ -1,13 +1,14 @@
-"""TEST INFRASTRUCTURE (oracle): the recursion circuit itself — proof allocation, Fiat-Shamir, composition check, DEEP
-answers + decommitments, FRI folding — in the order examples/multi-proofs/src/main.rs:66-139 (and
-examples/single-proof/src/main.rs) runs them, restated over cs.py / gadgets.py.
+"""The recursion circuit itself — proof allocation, Fiat-Shamir, composition check, DEEP answers + decommitments, FRI
+folding — in the order examples/multi-proofs/src/main.rs:66-139 (and examples/single-proof/src/main.rs) runs them,
+mirrored over cs.py / gadgets.py.
 
 Reference: components/recursive/data_structures/src/lib.rs (the *Var allocations), fiat_shamir/src/lib.rs:31-180,
 composition/src/{lib,plonk,poseidon,data_structures}.rs, answer/src/{lib,data_structures}.rs, folding/src/lib.rs:11-206.
 
 One thing cannot be restated: AnswerResults::compute walks two std HashSet<isize> ({0, -1} each) to build the shifted
 OODS points (answer/src/lib.rs:44-71), and Rust's HashSet order is seeded per process — the reference's own circuit
-differs from run to run in the order of those two pairs of blocks.  `shift_order` picks one of the four.
+differs from run to run in the order of those two pairs of blocks.  `shift_order` picks one of the four (the default is
+as good as any; tests/test_recursion_circuit.py finds the one each of the reference's fixtures was made with).
 """
 from __future__ import annotations
 
@@ -490,7 +491,8 @@ def fri_answers_for_log_size(samples, random_coeff, query_positions, queried_val
 def answer(pv: ProofVar, d, fs: FiatShamir, shift_order=((0, -1), (0, -1))) -> Answer:
     cs = pv.cs
     ans = Answer()
-    oods_point = G.pq_witness(cs, (fs.oods_point.x.value, fs.oods_point.y.value), ("oods_point",))  # main.rs:108
+    oods_point = G.pq_witness(cs, (fs.oods_point.x.value, fs.oods_point.y.value), ("copy", fs.oods_point.x.variable),
+                              ("copy", fs.oods_point.y.variable))  # examples/multi-proofs/src/main.rs:108
     step_plonk = G.canonic_coset(d.lp).step
     step_poseidon = G.canonic_coset(d.lq).step
     shifted_plonk, shifted_poseidon = {}, {}

@@ -24,6 +24,7 @@
 #include "primitives.hpp"
 #include "k_emulated.hpp"
 #include "verify.hpp"
+#include "k_witness.hpp"
 
 using namespace rsv;
 
@@ -81,6 +82,9 @@ struct rsv_ctx {
     size_t ws_fixed_bytes = 0;
     void* ws_rows = nullptr;   // k_row_hash output
     size_t ws_rows_bytes = 0;
+    void* ws_witness = nullptr;  // rsv_witness_eval_dev: the hints it asks the verifying pass for, and variables[var][proof]
+    size_t ws_witness_bytes = 0;
+    const struct rsv::ProofMeta* last_metas = nullptr;  // the parser's records of the last batch (inside ws_fixed)
     VerifyState* vs = nullptr;
     rsv_public_input* d_pi = nullptr;
     size_t d_pi_cap = 0;
@@ -190,6 +194,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->ws_fixed) (void)hipFree(c->ws_fixed);
     if (c->ws_rows) (void)hipFree(c->ws_rows);
+    if (c->ws_witness) (void)hipFree(c->ws_witness);
     if (c->d_pi) (void)hipFree(c->d_pi);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -447,3 +452,4 @@ int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint
 
 #include "verify_api.inc"
 #include "host_stream.inc"
+#include "witness_api.inc"

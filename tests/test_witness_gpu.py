@@ -1,0 +1,95 @@
+"""rsv_witness_eval (`-m gpu`): the recursion circuit's `variables` vector, evaluated on the GPU for a batch, against the
+values the circuit's gadgets compute when they are run — proof by proof, Python integers, CPU oracle's hints — on the
+same proofs (oracle/recursion_circuit.build_circuit; that code is pinned to the reference's fixtures by
+tests/test_recursion_circuit.py).  Program built on the GPU box from the GPU's own hints of a template proof."""
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+from tests.conftest import fixture_cfg, load_manifest, read_proof
+
+pytestmark = pytest.mark.gpu
+MAN = {e["file"]: e for e in load_manifest()}
+
+
+def _inputs(name):
+    return [(i, tuple(v)) for i, v in MAN[name]["inputs"]]
+
+
+def _oracle_variables(name, copies=1):
+    from oracle import recursion_circuit as rc
+    c, d, _ = rc.build_circuit(read_proof(name), ob, _inputs(name), copies)
+    c.check_arithmetics()
+    return np.array(c.variables, dtype=np.uint32), c, d
+
+
+@pytest.mark.parametrize("template,other", [("level10-1.bin", "level11-1.bin"), ("level2-1.bin", "level5-1.bin")])
+def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
+    """Program from `template` (GPU hints), batch = [template, other, a tampered copy, a proof of another shape, other]:
+    the rows of the two valid proofs of the shape equal the gadgets' `variables`, the tampered and the foreign proof are
+    flagged; the program equals the one extracted from the oracle's run (same instructions, same levels)."""
+    cfg = fixture_cfg(template)
+    prog = rsv.circuit.build_program(rsv, read_proof(template), cfg, _inputs(template))
+    want_t, c, d = _oracle_variables(template)
+    want_o, c_other, _ = _oracle_variables(other)
+    from oracle import recursion_circuit as rc
+    ref = rc.program.extract(c, d)
+    assert prog.n_vars == ref.n_vars and np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.level_offsets, ref.level_offsets)
+    wp = rsv.WitnessProgram(prog)
+    foreign = "level12-1.bin" if template != "level12-1.bin" else "level9-1.bin"
+    batch = [read_proof(template), read_proof(other), ob.tamper(read_proof(template), 7), read_proof(foreign), read_proof(other)]
+    variables, accept, reason = rsv.witness(batch, wp, _inputs(template))
+    assert accept.tolist() == [1, 1, 0, 0, 1] and reason[2] != 0
+    assert np.array_equal(variables[0], want_t)
+    assert np.array_equal(variables[1], want_o) and np.array_equal(variables[4], want_o)
+    # and the vector is a witness: every gate of ITS circuit holds on it (check_arithmetics, plonk_with_poseidon.rs:302-343;
+    # the gate list of `other`, not the template's: a few gate constants of the reference follow the witness, gadgets.pm_select)
+    c_other.variables = [tuple(int(x) for x in v) for v in variables[1]]
+    c_other.check_arithmetics()
+    wp.close()
+
+
+def test_witness_of_five_copies_in_one_circuit(rsv):
+    """examples/multi-proofs verifies recursive_proof_16_15.bin five times in one circuit (main.rs:64, 173-196):
+    the program of that circuit (about 330 000 variables; its 291 870 Plonk rows are the level1 fixture's 2^19)."""
+    name = "recursive_proof_16_15.bin"
+    prog = rsv.circuit.build_program(rsv, read_proof(name), fixture_cfg(name), _inputs(name), copies=5)
+    want, _, _ = _oracle_variables(name, 5)
+    wp = rsv.WitnessProgram(prog)
+    variables, accept, _ = rsv.witness([read_proof(name)] * 3, wp, _inputs(name))
+    assert accept.tolist() == [1, 1, 1]
+    for k in range(3):
+        assert np.array_equal(variables[k], want)
+    wp.close()
+
+
+def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
+    """Context.witness on tensors in HBM (n = 96 copies, two calls on one context: the second reuses the scratch), and the
+    API errors: a configuration that is not the program's, a misaligned output."""
+    import torch
+    name = "level12-1.bin"
+    prog = rsv.circuit.build_program(rsv, read_proof(name), fixture_cfg(name), _inputs(name))
+    want, _, _ = _oracle_variables(name)
+    wp = rsv.WitnessProgram(prog)
+    n = 96
+    blob, offsets = rsv.pack([read_proof(name)] * n)
+    dev = torch.device("cuda:0")
+    d_blob, d_off = torch.from_numpy(blob).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_vars = torch.zeros((n, prog.n_vars, 4), dtype=torch.int32, device=dev)
+    d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx = rsv.Context(0)
+    for _ in range(2):
+        d_vars.zero_()
+        ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(name))
+        ctx.synchronize()
+        got = d_vars.cpu().numpy().view(np.uint32)
+        assert d_acc.cpu().numpy().all() and all(np.array_equal(got[k], want) for k in (0, 1, n // 2, n - 1))
+    assert wp.scratch_bytes(n) > n * prog.n_vars * 16
+    other = rsv.WitnessProgram(prog)
+    other.shape.n_queries = 9  # what cfg() reports to the call below
+    with pytest.raises(rsv.RsvError) as e:
+        ctx.witness(other, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(name))
+    assert e.value.code == -2
+    ctx.close()
+    wp.close()
+    other.close()
