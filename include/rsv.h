@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RSV_M31_P 0x7fffffffu
-#define RSV_ABI_VERSION 3
+#define RSV_ABI_VERSION 4
 
 typedef enum rsv_status {
     RSV_OK = 0,

@@ -13,8 +13,8 @@ The gadgets run on ONE template proof per shape, with Python integers, exactly a
 proof; what they leave behind here is not the witness but the recipe (which gate or hint makes variable k).  The
 template's hints — Merkle paths, column values, the outputs of the Poseidon accelerator — come from the GPU's own
 verifying pass over the template (rsv_verify_hints), so building a program needs the HIP library like everything else in
-this package.  tests/ pin this very code to the reference: fed with the CPU oracle's hints instead, the circuit it builds
-reproduces the next fixture's sampled values column by column (oracle/recursion_circuit, tests/test_recursion_circuit.py).
+this package.  tests/ pin this very code to the reference: fed with the CPU checker's hints instead, the circuit it builds
+reproduces the next fixture's sampled values column by column (tests/test_recursion_circuit.py).
 """
 from __future__ import annotations
 

@@ -23,7 +23,10 @@ def _oracle_variables(name, copies=1):
     return np.array(c.variables, dtype=np.uint32), c, d
 
 
-@pytest.mark.parametrize("template,other", [("level10-1.bin", "level11-1.bin"), ("level2-1.bin", "level5-1.bin")])
+@pytest.mark.parametrize("template,other", [("level10-1.bin", "level11-1.bin"), ("level2-1.bin", "level5-1.bin"),
+                                            ("level1-5.bin", "level4-5.bin"),  # 80 queries, 300 000 variables
+                                            ("level7-1.bin", "level7-1.bin"),  # both components of one log size
+                                            ("small_proof.bin", "small_proof.bin")])  # one public input, last layer of 4
 def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
     """Program from `template` (GPU hints), batch = [template, other, a tampered copy, a proof of another shape, other]:
     the rows of the two valid proofs of the shape equal the gadgets' `variables`, the tampered and the foreign proof are
