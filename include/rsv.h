@@ -469,13 +469,18 @@ int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t*
 /* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and
  * writes d_variables [n][n_vars][4]: row i = the `variables` vector of the circuit that verifies proof i.
  * d_accept[i] = 1 iff proof i verified AND is of the program's shape; only those rows are defined (the others hold the
- * constants and zeros).  d_variables 16-byte aligned. */
+ * constants and zeros).  d_variables 16-byte aligned.
+ * d_flow [n][flow_count][32] + d_flow_swap [n][flow_count] (optional, both or neither; as rsv_hints_out::d_flow with
+ * flow_stride = the shape's flow_count): the PoseidonFlow of ONE copy of the verifier — the other thing the next prover
+ * needs; every copy invokes the same permutations, the wire indices of invocation k of copy c are the host's
+ * (circuit/program.py, Program.flow_wires).  Without them the records live in the context's scratch only. */
 int rsv_witness_eval_dev(rsv_ctx* ctx, const rsv_witness_program* prog, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
-                         const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t* d_variables, uint8_t* d_accept,
-                         uint8_t* d_reason);
+                         const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t* d_variables, uint32_t* d_flow,
+                         uint8_t* d_flow_swap, uint8_t* d_accept, uint8_t* d_reason);
 /* Same on host buffers. */
 int rsv_witness_eval(const rsv_witness_program* prog, const uint8_t* blob, const uint64_t* offsets, size_t n, const rsv_cfg_set* cfg,
-                     const rsv_public_input* pi, size_t n_pi, uint32_t* variables, uint8_t* accept, uint8_t* reason, int device);
+                     const rsv_public_input* pi, size_t n_pi, uint32_t* variables, uint32_t* flow, uint8_t* flow_swap, uint8_t* accept,
+                     uint8_t* reason, int device);
 
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).

@@ -194,9 +194,9 @@ def _load() -> ctypes.CDLL:
                                                       ctypes.POINTER(ctypes.c_void_p)]),
         "rsv_witness_program_destroy": (None, [vp]),
         "rsv_witness_scratch_bytes": (ctypes.c_int, [vp, sz, ctypes.POINTER(sz)]),
-        "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp]),
-        "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u8p, _u8p,
-                                            ctypes.c_int]),
+        "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp, vp, vp]),
+        "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u32p, _u8p,
+                                            _u8p, _u8p, ctypes.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what rsv.h declares
@@ -554,18 +554,22 @@ class WitnessProgram:
         return int(out.value)
 
 
-def witness(proofs: Sequence[bytes], program: WitnessProgram, inputs=STANDARD_INPUTS, device: int = 0):
-    """`variables` of the recursion circuit for every proof of a batch (rsv_witness_eval): uint32[n, n_vars, 4], accept, reason."""
+def witness(proofs: Sequence[bytes], program: WitnessProgram, inputs=STANDARD_INPUTS, device: int = 0, with_flow: bool = False):
+    """`variables` of the recursion circuit for every proof of a batch (rsv_witness_eval): uint32[n, n_vars, 4], accept, reason
+    [, flow uint32[n, flow_count, 32], flow_swap uint8[n, flow_count] with with_flow]."""
     blob, offsets = pack(proofs)
     n = len(proofs)
     variables = np.zeros((n, program.n_vars, 4), np.uint32)
     accept = np.zeros(n, np.uint8)
     reason = np.zeros(n, np.uint8)
+    flow = np.zeros((n, program.shape.flow_count, 32), np.uint32) if with_flow else None
+    swap = np.zeros((n, program.shape.flow_count), np.uint8) if with_flow else None
     pi = make_inputs(inputs)
     _check(lib.rsv_witness_eval(program._h, blob.ctypes.data_as(_u8p), offsets.ctypes.data_as(_u64p), n, prepare_cfg(program.cfg(), n).ref(), pi,
-                                len(list(inputs)), variables.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device),
+                                len(list(inputs)), variables.ctypes.data_as(_u32p), flow.ctypes.data_as(_u32p) if with_flow else None,
+                                swap.ctypes.data_as(_u8p) if with_flow else None, accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device),
            "rsv_witness_eval")
-    return variables, accept, reason
+    return (variables, accept, reason, flow, swap) if with_flow else (variables, accept, reason)
 
 
 def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: int, inputs=STANDARD_INPUTS, device: int = 0):
@@ -725,14 +729,18 @@ class Context:
         _check(lib.rsv_verify_hints_dev(self._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
                                         ctypes.byref(ho), d_accept.data_ptr(), ptr(d_reason)), "rsv_verify_hints_dev")
 
-    def witness(self, program: WitnessProgram, d_blob, d_offsets, n: int, d_variables, d_accept, d_reason=None, inputs=STANDARD_INPUTS):
-        """rsv_witness_eval_dev: d_variables uint32[n, n_vars, 4] in HBM; enqueued on the context's streams."""
+    def witness(self, program: WitnessProgram, d_blob, d_offsets, n: int, d_variables, d_accept, d_reason=None, inputs=STANDARD_INPUTS,
+                d_flow=None, d_flow_swap=None):
+        """rsv_witness_eval_dev: d_variables uint32[n, n_vars, 4] in HBM (optionally the PoseidonFlow: d_flow uint32[n, flow_count,
+        32], d_flow_swap uint8[n, flow_count]); enqueued on the context's streams."""
         pi = make_inputs(inputs)
         pc = self.prepare_cfg(program.cfg(), n)
         self.acquire_from_torch()
         self._keep(pc, None)
         _check(lib.rsv_witness_eval_dev(self._h, program._h, d_blob.data_ptr(), d_offsets.data_ptr(), n, pc.ref(), pi, len(list(inputs)),
-                                        d_variables.data_ptr(), d_accept.data_ptr(), d_reason.data_ptr() if d_reason is not None else None),
+                                        d_variables.data_ptr(), d_flow.data_ptr() if d_flow is not None else None,
+                                        d_flow_swap.data_ptr() if d_flow_swap is not None else None, d_accept.data_ptr(),
+                                        d_reason.data_ptr() if d_reason is not None else None),
                "rsv_witness_eval_dev")
 
     def accept_bitmap(self, d_accept, n: int, d_bitmap, d_count=None):

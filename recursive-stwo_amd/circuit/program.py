@@ -22,7 +22,7 @@ template proof (circuit/verifier.py), and what they did is written down as one i
 Instructions are sorted by dependency depth ("levels"): everything inside a level only reads variables of earlier levels,
 so the GPU runs one launch per level over (instructions of the level) x (proofs).  The hash chains cost no depth — the
 outputs of the Poseidon accelerator are hints read from the flow records — which leaves the arithmetic chains (the
-composition accumulator, the folds): a few thousand levels for a quarter of a million variables.
+composition accumulator, the folds): 265 to 300 levels for 39 000 to 330 000 variables.
 """
 from __future__ import annotations
 
@@ -54,19 +54,50 @@ def sample_offsets():
 
 class Program:
     """instr: uint32[n_instr, 8] sorted by level; level_offsets: uint32[n_levels + 1]; n_vars; shape = what a proof must
-    look like for this program to apply."""
+    look like for this program to apply; flow_wires: uint32[copies * flow_count, 5] = the wire indices of the circuit's
+    PoseidonFlow entries (PoseidonEntry::wire of r1..r4, SwapOption::addr; plonk_with_poseidon.rs:117-128), constants of
+    the shape that go with the hashes rsv_witness_eval_dev returns in d_flow (invocation k of copy c = row c * flow_count + k)."""
 
-    def __init__(self, instr, level_offsets, n_vars, shape):
+    def __init__(self, instr, level_offsets, n_vars, shape, flow_wires=None):
         self.instr, self.level_offsets, self.n_vars, self.shape = instr, level_offsets, n_vars, shape
+        self.flow_wires = flow_wires if flow_wires is not None else np.zeros((shape["copies"] * shape["flow_count"], 5), np.uint32)
 
     def save(self, path):
         np.savez_compressed(path, instr=self.instr, level_offsets=self.level_offsets, n_vars=np.array([self.n_vars]),
-                            shape=np.array([self.shape[k] for k in SHAPE_KEYS], dtype=np.uint32))
+                            shape=np.array([self.shape[k] for k in SHAPE_KEYS], dtype=np.uint32), flow_wires=self.flow_wires)
+
+    RAW_MAGIC = 0x57565352  # "RSVW"
+
+    def save_raw(self, path):
+        """The flat file the C++ host mirror loads (host/recursive_stwo.hpp, WitnessProgram::load): "RSVW", version 1, n_vars,
+        n_levels, the 9 shape words, level_offsets, instr, flow_wires."""
+        head = np.array([self.RAW_MAGIC, 1, self.n_vars, len(self.level_offsets) - 1] + [self.shape[k] for k in SHAPE_KEYS], dtype=np.uint32)
+        with open(path, "wb") as f:
+            f.write(head.tobytes())
+            f.write(np.ascontiguousarray(self.level_offsets, dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(self.instr, dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(self.flow_wires, dtype=np.uint32).tobytes())
+
+    @staticmethod
+    def load_raw(path):
+        w = np.fromfile(path, dtype=np.uint32)
+        if len(w) < 13 or w[0] != Program.RAW_MAGIC or w[1] != 1:
+            raise ValueError(f"not a witness program: {path}")
+        n_vars, n_levels = int(w[2]), int(w[3])
+        shape = dict(zip(SHAPE_KEYS, (int(x) for x in w[4:13])))
+        levels = w[13:13 + n_levels + 1].copy()
+        at = 13 + n_levels + 1
+        n_flow = shape["copies"] * shape["flow_count"]
+        if len(w) != at + n_vars * INSTR_WORDS + 5 * n_flow:
+            raise ValueError(f"truncated witness program: {path}")
+        instr = w[at:at + n_vars * INSTR_WORDS].reshape(n_vars, INSTR_WORDS).copy()
+        return Program(instr, levels, n_vars, shape, w[at + n_vars * INSTR_WORDS:].reshape(n_flow, 5).copy())
 
     @staticmethod
     def load(path):
         z = np.load(path)
-        return Program(z["instr"], z["level_offsets"], int(z["n_vars"][0]), dict(zip(SHAPE_KEYS, (int(x) for x in z["shape"]))))
+        return Program(z["instr"], z["level_offsets"], int(z["n_vars"][0]), dict(zip(SHAPE_KEYS, (int(x) for x in z["shape"]))),
+                       z["flow_wires"])
 
 
 SHAPE_KEYS = ("lp", "lq", "pow_bits", "blowup", "log_last", "nq", "n_inner", "flow_count", "copies")
@@ -157,7 +188,8 @@ def extract(cs, d, copies=1) -> Program:
     level_offsets = np.searchsorted(depth[order], np.arange(n_levels + 1)).astype(np.uint32)
     shape = {"lp": d.lp, "lq": d.lq, "pow_bits": d.pow_bits, "blowup": d.blowup, "log_last": d.log_last, "nq": d.nq,
              "n_inner": d.n_inner, "flow_count": flow_per_copy, "copies": copies}
-    return Program(instr, level_offsets, n_vars, shape)
+    flow_wires = np.array([[e1[0], e2[0], e3[0], e4[0], addr] for (e1, e2, e3, e4, addr, _sw) in cs.flow], dtype=np.uint32)
+    return Program(instr, level_offsets, n_vars, shape, flow_wires)
 
 
 def interpret(program: Program, sources):

@@ -25,6 +25,8 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -405,6 +407,76 @@ struct PoseidonFlow {
         uint32_t lg = 0;
         while (((size_t)1 << lg) < 6 * padded) lg++;
         return lg;
+    }
+};
+
+// The circuit's `variables: Vec<QM31>` (constraint_system/src/plonk_with_poseidon.rs:19) for batches of proofs of one
+// shape: a witness program (include/rsv.h; built per shape by recursive-stwo_amd/circuit, stored with Program.save_raw)
+// loaded from a file and evaluated on the GPU.  variables(proofs)[i] is what PlonkWithPoseidonConstraintSystem holds after
+// the loop body of examples/multi-proofs/src/main.rs:66-139 ran `copies` times on proof i.
+struct WitnessProgram {
+    rsv_witness_program* handle = nullptr;
+    rsv_witness_shape shape{};
+    uint32_t n_vars = 0;
+
+    WitnessProgram() = default;
+    WitnessProgram(const WitnessProgram&) = delete;
+    WitnessProgram& operator=(const WitnessProgram&) = delete;
+    WitnessProgram(WitnessProgram&& o) noexcept : handle(o.handle), shape(o.shape), n_vars(o.n_vars) { o.handle = nullptr; }
+    ~WitnessProgram() { if (handle) rsv_witness_program_destroy(handle); }
+
+    // PoseidonEntry::wire of r1..r4 and SwapOption::addr of every invocation of every copy (shape constants)
+    std::vector<std::array<uint32_t, 5>> flow_wires;
+
+    // file = "RSVW" | version 1 | n_vars | n_levels | rsv_witness_shape (9 words) | level_offsets[n_levels + 1] | instr[n_vars][8]
+    //        | flow_wires[copies * flow_count][5]
+    static WitnessProgram load(const std::string& path) {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot open witness program " + path);
+        std::vector<uint32_t> w;
+        uint32_t buf[4096];
+        size_t got;
+        while ((got = std::fread(buf, 4, 4096, f)) > 0) w.insert(w.end(), buf, buf + got);
+        std::fclose(f);
+        if (w.size() < 13 || w[0] != 0x57565352u || w[1] != 1) throw std::runtime_error("not a witness program: " + path);
+        const uint32_t n_vars = w[2], n_levels = w[3];
+        WitnessProgram p;
+        std::memcpy(&p.shape, &w[4], sizeof(rsv_witness_shape));
+        const size_t n_flow = (size_t)p.shape.copies * p.shape.flow_count, at = 13 + (size_t)n_levels + 1 + (size_t)n_vars * 8;
+        if (w.size() != at + 5 * n_flow) throw std::runtime_error("truncated witness program: " + path);
+        p.flow_wires.resize(n_flow);
+        std::memcpy(p.flow_wires.data(), &w[at], 20 * n_flow);
+        p.n_vars = n_vars;
+        check(rsv_witness_program_create(&w[13 + n_levels + 1], n_vars, &w[13], n_levels, n_vars, &p.shape, default_device(), &p.handle),
+              "rsv_witness_program_create");
+        return p;
+    }
+    PcsConfig config() const { return {shape.pow_bits, FriConfig::make(shape.log_last, shape.log_blowup, shape.n_queries)}; }
+
+    // one vector per proof; accept[i] = verified and of the program's shape (the others' vectors are left empty)
+    std::vector<std::vector<QM31>> variables(const std::vector<std::vector<uint8_t>>& proofs, const Inputs& inputs,
+                                             std::vector<uint8_t>& accept, std::vector<uint8_t>& reason) const {
+        const size_t n = proofs.size();
+        std::vector<uint64_t> offsets(n + 1, 0);
+        for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + proofs[i].size();
+        std::vector<uint8_t> blob(offsets[n]);
+        for (size_t i = 0; i < n; i++) std::memcpy(blob.data() + offsets[i], proofs[i].data(), proofs[i].size());
+        std::vector<uint32_t> vars(n * (size_t)n_vars * 4);
+        accept.assign(n, 0);
+        reason.assign(n, 0);
+        const rsv_pcs_config abi_cfg = config().abi();
+        const rsv_cfg_set cfg_set{&abi_cfg, 1, nullptr};
+        auto pi = abi_inputs(inputs);
+        check(rsv_witness_eval(handle, blob.data(), offsets.data(), n, &cfg_set, pi.data(), pi.size(), vars.data(), nullptr, nullptr,
+                               accept.data(), reason.data(), default_device()), "rsv_witness_eval");
+        std::vector<std::vector<QM31>> out(n);
+        for (size_t i = 0; i < n; i++) {
+            if (!accept[i]) continue;
+            out[i].resize(n_vars);
+            for (uint32_t k = 0; k < n_vars; k++)
+                for (int c = 0; c < 4; c++) out[i][k][c] = vars[((size_t)i * n_vars + k) * 4 + c];
+        }
+        return out;
     }
 };
 

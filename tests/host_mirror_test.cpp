@@ -200,6 +200,39 @@ static void test_poseidon_flow(const std::vector<uint8_t>& small, const std::vec
     EXPECT(threw);
 }
 
+// The circuit's `variables` for a batch: the program file is written by the Python side of the host layer
+// (recursive-stwo_amd/circuit, Program.save_raw) for the shape of level10-1.bin; level11-1.bin is another proof of that
+// shape, level12-1.bin is not.  What the reference's check_arithmetics looks at first — the four fixed variables 0, 1, i, j
+// (plonk_with_poseidon.rs:61-64) — and the statement words the proof allocation pushes next (data_structures/src/lib.rs:36-46).
+static void test_witness(const std::string& program_path, const std::vector<uint8_t>& l10, const std::vector<uint8_t>& l11,
+                         const std::vector<uint8_t>& l12) {
+    WitnessProgram prog = WitnessProgram::load(program_path);
+    EXPECT(prog.shape.log_size_plonk == 16 && prog.shape.log_size_poseidon == 15 && prog.shape.n_queries == 10 && prog.shape.copies == 1);
+    EXPECT(prog.flow_wires.size() == prog.shape.flow_count && prog.flow_wires[0][0] != 0 && prog.flow_wires[0][4] == 0);
+    Inputs inputs = {{1, QM31{1, 0, 0, 0}}, {2, QM31{0, 1, 0, 0}}, {3, QM31{0, 0, 1, 0}}};
+    std::vector<uint8_t> accept, reason;
+    auto tampered = l10;
+    tampered[60000] ^= 1;
+    auto vars = prog.variables({l10, l11, tampered, l12}, inputs, accept, reason);
+    EXPECT(accept == (std::vector<uint8_t>{1, 1, 0, 0}) && reason[2] != 0);
+    EXPECT(vars[0].size() == prog.n_vars && vars[1].size() == prog.n_vars && vars[2].empty() && vars[3].empty());
+    for (int k = 0; k < 2; k++) {
+        EXPECT((vars[k][0] == QM31{0, 0, 0, 0}) && (vars[k][1] == QM31{1, 0, 0, 0}) && (vars[k][2] == QM31{0, 1, 0, 0}) &&
+               (vars[k][3] == QM31{0, 0, 1, 0}));
+    }
+    EXPECT(vars[0] != vars[1]);
+    // the first witnesses are the statement: log sizes, then the two claimed sums as they stand in the proof
+    for (int k = 0; k < 2; k++) {
+        const auto& proof = k == 0 ? l10 : l11;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(proof.data());
+        size_t at = 4;
+        while (at < vars[k].size() && !(vars[k][at] == QM31{16, 0, 0, 0} && vars[k][at + 1] == QM31{15, 0, 0, 0})) at++;
+        EXPECT(at + 3 < vars[k].size());
+        EXPECT((vars[k][at + 2] == QM31{w[2], w[3], w[4], w[5]}) && (vars[k][at + 3] == QM31{w[6], w[7], w[8], w[9]}));
+    }
+    printf("witness: %u variables per proof, accept = %d %d %d %d\n", prog.n_vars, accept[0], accept[1], accept[2], accept[3]);
+}
+
 int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "tests/golden/proofs";
     auto small = read_file(dir + "/small_proof.bin");
@@ -211,6 +244,7 @@ int main(int argc, char** argv) {
     test_verify(small);
     test_hints(small);
     test_poseidon_flow(small, read_file(dir + "/recursive_proof_16_15.bin"), read_file(dir + "/level1-5.bin"));
+    if (argc > 2) test_witness(argv[2], read_file(dir + "/level10-1.bin"), read_file(dir + "/level11-1.bin"), read_file(dir + "/level12-1.bin"));
     printf("host mirror: all tests passed\n");
     return 0;
 }

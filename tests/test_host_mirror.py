@@ -23,9 +23,18 @@ def test_host_mirror_compiles(tmp_path):
 @pytest.mark.gpu
 def test_host_mirror_runs_reference_tests(tmp_path):
     exe = build(tmp_path)
-    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "proofs")], capture_output=True, text=True)
+    # the witness program of the level10 shape, written by the Python side of the host layer and loaded by the C++ side
+    import rsvload
+    from tests.conftest import fixture_cfg, read_proof
+    rsv = rsvload.load_package()
+    prog = rsv.circuit.build_program(rsv, read_proof("level10-1.bin"), fixture_cfg("level10-1.bin"))
+    path = os.path.join(str(tmp_path), "level10.rsvw")
+    prog.save_raw(path)
+    back = rsv.circuit.Program.load_raw(path)
+    assert back.n_vars == prog.n_vars and back.shape == prog.shape and (back.instr == prog.instr).all()
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "proofs"), path], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "all tests passed" in out.stdout
+    assert "all tests passed" in out.stdout and f"witness: {prog.n_vars} variables per proof, accept = 1 1 0 0" in out.stdout
 
 
 def _build_example(tmp_path, name):

@@ -109,6 +109,20 @@ def _program_for(name, copies=1):
     return rc.program.extract(c, d, copies), c, d
 
 
+def test_program_files_round_trip(tmp_path):
+    prog, _, _ = _program_for("level12-1.bin")
+    for save, load, name in ((prog.save, rc.program.Program.load, "p.npz"), (prog.save_raw, rc.program.Program.load_raw, "p.rsvw")):
+        path = str(tmp_path / name)
+        save(path)
+        back = load(path)
+        assert back.n_vars == prog.n_vars and back.shape == prog.shape
+        assert np.array_equal(back.instr, prog.instr) and np.array_equal(back.level_offsets, prog.level_offsets)
+    with open(str(tmp_path / "junk"), "wb") as f:
+        f.write(b"\0" * 100)
+    with pytest.raises(ValueError):
+        rc.program.Program.load_raw(str(tmp_path / "junk"))
+
+
 def test_program_depends_on_the_shape_only():
     """level10-1 and level11-1 are two different proofs of one shape: the programs extracted from them are identical, so a
     program built from one template serves every proof of its shape — also where the reference's own gate list follows the

@@ -41,8 +41,28 @@ def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
     wp = rsv.WitnessProgram(prog)
     foreign = "level12-1.bin" if template != "level12-1.bin" else "level9-1.bin"
     batch = [read_proof(template), read_proof(other), ob.tamper(read_proof(template), 7), read_proof(foreign), read_proof(other)]
-    variables, accept, reason = rsv.witness(batch, wp, _inputs(template))
+    variables, accept, reason, flow, swap = rsv.witness(batch, wp, _inputs(template), with_flow=True)
     assert accept.tolist() == [1, 1, 0, 0, 1] and reason[2] != 0
+    # the PoseidonFlow that comes with it: the hashes == the CPU checker's record for record; its wire indices (constants
+    # of the shape, Program.flow_wires) point at Poseidon gates whose two operands ARE the entry's hash in this proof's
+    # variables (check_poseidon_invocations, plonk_with_poseidon.rs:468-490), and the swap address holds the swap bit
+    want_flow = ob.poseidon_flow(read_proof(other), _inputs(other))
+    assert np.array_equal(flow[1], want_flow[:, :32]) and np.array_equal(swap[1], want_flow[:, 32].astype(np.uint8))
+    at = np.empty(prog.n_vars, np.int64)
+    at[prog.instr[:, 1]] = np.arange(prog.n_vars)
+    P_ = rsv.circuit.program
+    checked = 0
+    for k in range(0, prog.shape["flow_count"], 7):
+        for j in range(4):
+            w = int(prog.flow_wires[k, j])
+            if w:
+                op, _, a, b = (int(x) for x in prog.instr[at[w], :4])
+                assert op == P_.MUL
+                assert np.array_equal(np.concatenate([variables[1][a], variables[1][b]]), flow[1][k, 8 * j:8 * j + 8]), (k, j)
+                checked += 1
+        addr = int(prog.flow_wires[k, 4])
+        assert variables[1][addr].tolist() == [int(swap[1][k]), 0, 0, 0] if addr else swap[1][k] == 0
+    assert checked > prog.shape["flow_count"] // 7
     assert np.array_equal(variables[0], want_t)
     assert np.array_equal(variables[1], want_o) and np.array_equal(variables[4], want_o)
     # and the vector is a witness: every gate of ITS circuit holds on it (check_arithmetics, plonk_with_poseidon.rs:302-343;
@@ -77,7 +97,7 @@ def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
     n = 96
     blob, offsets = rsv.pack([read_proof(name)] * n)
     dev = torch.device("cuda:0")
-    d_blob, d_off = torch.from_numpy(blob).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
     d_vars = torch.zeros((n, prog.n_vars, 4), dtype=torch.int32, device=dev)
     d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
     ctx = rsv.Context(0)
