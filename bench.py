@@ -440,6 +440,39 @@ def main():
                     "frac": m * ebytes / edt / 1e9 / HBM_PEAK_GBPS}
         del d_l, d_r, d_s, d_rows
 
+    # SURVEY §8f.1 widening: the recursion circuit's `variables` for a batch (rsv_witness_eval_dev): 1 024 proofs of the
+    # level10 shape, program built here from the GPU's own hints of the fixture; HBM streaming
+    witness = None
+    if args.perm_log2 > 0 and world == 1 and rank == 0:
+        wname = "level10-1.bin"
+        wproof = read_fixture(wname)
+        wcfg = fixture_configs(rsv, [wname])[0]
+        t1 = time.perf_counter()
+        wprog = rsv.circuit.build_program(rsv, wproof, wcfg)
+        wbuild = time.perf_counter() - t1
+        wp = rsv.WitnessProgram(wprog, dev_index)
+        wn = 1024
+        wblob, woff = rsv.pack([wproof] * wn)
+        d_wblob, d_woff = torch.from_numpy(wblob.copy()).to(dev), torch.from_numpy(woff.astype(np.int64)).to(dev)
+        d_wvars = torch.empty((wn, wprog.n_vars, 4), dtype=torch.int32, device=dev)
+        d_wacc = torch.zeros(wn, dtype=torch.uint8, device=dev)
+        ctx.witness(wp, d_wblob, d_woff, wn, d_wvars, d_wacc)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.witness(wp, d_wblob, d_woff, wn, d_wvars, d_wacc)
+        ctx.synchronize()
+        wdt = (time.perf_counter() - t1) / reps
+        if not bool(d_wacc.all().item()):
+            raise SystemExit("witness leg: a genuine proof was not accepted")
+        witness = {"proofs_per_s": wn / wdt, "ms": wdt * 1e3, "proofs": wn, "fixture": wname, "variables_per_proof": wprog.n_vars,
+                   "levels": int(len(wprog.level_offsets) - 1), "output_GB": wn * wprog.n_vars * 16 / 1e9, "program_build_s": wbuild,
+                   "includes": "the verifying pass with the hint outputs the program reads, one launch per level, the transpose "
+                               "(split and roofline: tools/bench_witness.py, profiles/r3_witness_*.json)"}
+        wp.close()
+        del d_wblob, d_wvars
+
     cpu = None
     host_path = None
     sample = args.cpu_sample
@@ -492,6 +525,7 @@ def main():
                    "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
                        "gloo (rehearsal)" if rehearsal else ("nccl/RCCL" if world > 1 else "none (1 rank)")))},
         "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "valu": valu, "emulated_poseidon2": emulated,
+        "recursion_circuit_witness": witness,
     }
     print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_witness_transpose(const uint4* __restri
                                                            uint32_t n) {
     __shared__ uint4 tile[32][33];
     const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
-    const uint32_t p0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const uint32_t k0 = blockIdx.x * 32, p0 = blockIdx.y * 32;  // proofs (at most 2^20) on the y axis, whose limit is 65 535 blocks
     for (uint32_t j = ty; j < 32; j += 8) {
         const uint32_t k = k0 + j, p = p0 + tx;
         if (k < n_vars && p < n) tile[j][tx] = vars[(size_t)k * n + p];
