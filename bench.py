@@ -448,13 +448,12 @@ def main():
         wproof = read_fixture(wname)
         wcfg = fixture_configs(rsv, [wname])[0]
         t1 = time.perf_counter()
-        wprog = rsv.circuit.build_program(rsv, wproof, wcfg)
+        wp = rsv.WitnessProgram.build(wproof, wcfg, device=dev_index)
         wbuild = time.perf_counter() - t1
-        wp = rsv.WitnessProgram(wprog, dev_index)
         wn = 1024
         wblob, woff = rsv.pack([wproof] * wn)
         d_wblob, d_woff = torch.from_numpy(wblob.copy()).to(dev), torch.from_numpy(woff.astype(np.int64)).to(dev)
-        d_wvars = torch.empty((wn, wprog.n_vars, 4), dtype=torch.int32, device=dev)
+        d_wvars = torch.empty((wn, wp.n_vars, 4), dtype=torch.int32, device=dev)
         d_wacc = torch.zeros(wn, dtype=torch.uint8, device=dev)
         ctx.witness(wp, d_wblob, d_woff, wn, d_wvars, d_wacc)
         ctx.synchronize()
@@ -466,8 +465,8 @@ def main():
         wdt = (time.perf_counter() - t1) / reps
         if not bool(d_wacc.all().item()):
             raise SystemExit("witness leg: a genuine proof was not accepted")
-        witness = {"proofs_per_s": wn / wdt, "ms": wdt * 1e3, "proofs": wn, "fixture": wname, "variables_per_proof": wprog.n_vars,
-                   "levels": int(len(wprog.level_offsets) - 1), "output_GB": wn * wprog.n_vars * 16 / 1e9, "program_build_s": wbuild,
+        witness = {"proofs_per_s": wn / wdt, "ms": wdt * 1e3, "proofs": wn, "fixture": wname, "variables_per_proof": wp.n_vars,
+                   "levels": wp.n_levels, "output_GB": wn * wp.n_vars * 16 / 1e9, "program_build_s": wbuild,
                    "includes": "the verifying pass with the hint outputs the program reads, one launch per level, the transpose "
                                "(split and roofline: tools/bench_witness.py, profiles/r3_witness_*.json)"}
         wp.close()

@@ -443,15 +443,15 @@ int rsv_transcript_batch(const uint8_t* blob, const uint64_t* offsets, size_t n,
  * new_qm31 call of the gadgets, in call order (:140-283); the trace columns a_val / b_val / c_val are that vector read
  * through the wires (:571-618).  The reference computes it by running the gadgets on one proof at a time on the CPU.
  * Which gate or hint produces variable k is the same for every proof of one shape (statement sizes + PcsConfig), so
- * here the gadgets are run once per shape on the host (recursive-stwo_amd/circuit/: a mirror of the reference's
- * ConstraintSystemRef / M31Var / ... / FiatShamirResults / CompositionCheck / AnswerResults / FoldingResults that writes
- * down what it did) and the resulting PROGRAM — one instruction per variable, sorted by dependency depth — is evaluated
+ * here the gadgets are run once per shape on the host (rsv_witness_program_build: csrc/circuit_*.hpp, a mirror of the
+ * reference's ConstraintSystemRef / M31Var / ... / FiatShamirResults / CompositionCheck / AnswerResults / FoldingResults
+ * that writes down what it did) and the resulting PROGRAM — one instruction per variable, sorted by dependency depth — is evaluated
  * on the GPU for a whole batch, from the hints of the verifying pass (proof words, PoseidonFlow records, per-query
  * column values).  The circuit is `copies` copies of the verifier in one constraint system, as
  * examples/multi-proofs/src/main.rs:66-139 builds it (`multipliers`); every copy verifies the same proof.
  *
  * Instruction = 8 u32: op, dst, a, b, imm0..imm3 (ops: recursive-stwo_amd/csrc/k_witness.hpp WitnessOp; the table with
- * their meaning heads recursive-stwo_amd/circuit/program.py).  rsv_witness_program_create checks every index the device
+ * their meaning heads recursive-stwo_amd/witness_program.py).  rsv_witness_program_create checks every index the device
  * will use (RSV_E_RANGE otherwise) and keeps a copy in HBM. */
 typedef struct rsv_witness_program rsv_witness_program;
 typedef struct {
@@ -464,6 +464,19 @@ typedef struct {
 int rsv_witness_program_create(const uint32_t* instr, size_t n_instr, const uint32_t* level_offsets, size_t n_levels,
                                uint32_t n_vars, const rsv_witness_shape* shape, int device, rsv_witness_program** out);
 void rsv_witness_program_destroy(rsv_witness_program* prog);
+/* The program of the shape of `proof` (a template: any proof of that shape that verifies under cfg with these public
+ * inputs, else RSV_E_RANGE), for a circuit of `copies` copies of the verifier: runs the library's mirror of the
+ * reference's gadgets (csrc/circuit_{cs,gadgets,verifier}.hpp: ConstraintSystemRef, M31Var .. QM31Var, BitsVar,
+ * Poseidon2HalfVar, ChannelVar, the Merkle hasher, circle points, LinePolyVar, query positions; PlonkWithPoseidonProofVar,
+ * FiatShamirResults, CompositionCheck, AnswerResults, FoldingResults) once over the template on the host, fed with the
+ * hints of the GPU's verifying pass over it.  ~0.1 s per 50 000 variables. */
+int rsv_witness_program_build(const uint8_t* proof, size_t len, const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
+                              uint32_t copies, int device, rsv_witness_program** out);
+/* Sizes, then the arrays (any pointer may be NULL): instr [n_vars][8], level_offsets [n_levels + 1], flow_wires
+ * [copies * flow_count][5] = PoseidonEntry::wire of r1..r4 and SwapOption::addr of every invocation (constants of the
+ * shape; known to built programs only, RSV_E_SIZE otherwise) — what rsv_witness_program_create takes back. */
+int rsv_witness_program_info(const rsv_witness_program* prog, uint32_t* n_vars, uint32_t* n_levels, rsv_witness_shape* shape);
+int rsv_witness_program_export(const rsv_witness_program* prog, uint32_t* instr, uint32_t* level_offsets, uint32_t* flow_wires);
 /* HBM the context will hold for a batch of n proofs (hints of the verifying pass + variables[var][proof]). */
 int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t* bytes);
 /* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and
@@ -473,7 +486,7 @@ int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t*
  * d_flow [n][flow_count][32] + d_flow_swap [n][flow_count] (optional, both or neither; as rsv_hints_out::d_flow with
  * flow_stride = the shape's flow_count): the PoseidonFlow of ONE copy of the verifier — the other thing the next prover
  * needs; every copy invokes the same permutations, the wire indices of invocation k of copy c are the host's
- * (circuit/program.py, Program.flow_wires).  Without them the records live in the context's scratch only. */
+ * (rsv_witness_program_export, flow_wires).  Without them the records live in the context's scratch only. */
 int rsv_witness_eval_dev(rsv_ctx* ctx, const rsv_witness_program* prog, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
                          const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint32_t* d_variables, uint32_t* d_flow,
                          uint8_t* d_flow_swap, uint8_t* d_accept, uint8_t* d_reason);

@@ -1,10 +1,12 @@
-"""The reference's Plonk-with-Poseidon constraint system and its field variables, mirrored (host side of the witness program).
+"""TEST INFRASTRUCTURE (oracle): the reference's Plonk-with-Poseidon constraint system and its field variables, restated.
 
 What the reference's recursion circuit leaves behind for the next prover is `variables: Vec<QM31>` plus the gate lists
 (`a_wire / b_wire / c_wire / op / poseidon_wire / enforce_c_m31`) and the PoseidonFlow
 (constraint_system/src/plonk_with_poseidon.rs:17-41).  Every gadget call appends to them in program order, so the
-vector is only reproduced by replaying the gadgets in that order; this module does that with plain Python integers, once
-per proof shape, and keeps for every variable HOW it came to be (`origin`) — the witness program (program.py).
+vector is only reproduced by replaying the gadgets in that order; this module does that with plain Python integers and
+keeps for every variable HOW it came to be (`origin`), from which program.py derives a witness program.  It is an
+independent restatement: the library's own mirror of the gadgets is C++ (recursive-stwo_amd/csrc/circuit_*.hpp).
+Only tests/ and the parity tooling import this package; the product never does.
 
 Values: M31 = int, CM31 = (re, im), QM31 = (a0, a1, a2, a3) = (a0 + a1 i) + (a2 + a3 i) j, i^2 = -1, j^2 = 2 + i.
 """

@@ -1,4 +1,4 @@
-"""The reference's circuit gadgets over cs.py, mirrored in allocation order.
+"""TEST INFRASTRUCTURE (oracle): the reference's circuit gadgets over cs.py, restated in allocation order.
 
 bits (primitives/bits/src/lib.rs), Poseidon2HalfVar (primitives/poseidon31/src/lib.rs), ChannelVar
 (primitives/channel/src/lib.rs), Poseidon31MerkleHasherVar (primitives/merkle/src/lib.rs), circle points

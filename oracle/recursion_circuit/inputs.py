@@ -4,13 +4,13 @@
 tests/)."""
 from __future__ import annotations
 
-from . import circuit
+from . import shape
 
 
 def build_inputs(proof: bytes, ob, inputs=None):
     """-> ProofData with .decommit[t][i], .first_layer[i], .inner_layers[log_size][i]; queries in transcript order."""
     inputs = ob.STANDARD_INPUTS if inputs is None else inputs
-    d = circuit.parse_proof(proof)
+    d = shape.parse_proof(proof)
     sib, pos, depth = ob.trace_paths(proof, d.nq, d.M, inputs)
     assert [int(x) for x in depth] == [max(d.A, d.B)] * 3 + [d.M]
     fsib, fcols = ob.fri_paths(proof, d.nq, d.M, 1 + d.n_inner, inputs)

@@ -1,4 +1,4 @@
-"""What the circuit is fed: the proof as the reference's `*Var` types see it and the per-query hint structs of
+"""TEST INFRASTRUCTURE (oracle): what the circuit is fed: the proof as the reference's `*Var` types see it and the per-query hint structs of
 components/hints — SinglePathMerkleProof (decommit.rs:10-19), SinglePairMerkleProof (folding.rs:20-29) — assembled from
 the buffers of rsv_hints_out (include/rsv.h)."""
 from __future__ import annotations

@@ -11,9 +11,9 @@ from __future__ import annotations
 import numpy as np
 
 
-from . import circuit
-G = circuit.gadgets
-P = circuit.cs.P
+from . import cs as C
+from . import gadgets as G
+from .cs import P
 
 PREPROCESSED = ("a_wire", "b_wire", "c_wire", "op", "mult_a", "mult_b", "mult_c", "poseidon_wire", "mult_poseidon", "enforce_c_m31")
 
@@ -112,7 +112,6 @@ class PointEvaluator:
     of all rows are computed once (f(point) = sum_i w_i v_i), so a column costs one dot product."""
 
     def __init__(self, log_size, point):
-        C = circuit.cs
         n = log_size
         half = G.canonic_half_coset(n)
         hx, hy = _coset_points(half.initial_index, half.step_size, n - 1)

@@ -1,6 +1,6 @@
-"""The recursion circuit itself — proof allocation, Fiat-Shamir, composition check, DEEP answers + decommitments, FRI
+"""TEST INFRASTRUCTURE (oracle): the recursion circuit itself — proof allocation, Fiat-Shamir, composition check, DEEP answers + decommitments, FRI
 folding — in the order examples/multi-proofs/src/main.rs:66-139 (and examples/single-proof/src/main.rs) runs them,
-mirrored over cs.py / gadgets.py.
+restated over cs.py / gadgets.py.
 
 Reference: components/recursive/data_structures/src/lib.rs (the *Var allocations), fiat_shamir/src/lib.rs:31-180,
 composition/src/{lib,plonk,poseidon,data_structures}.rs, answer/src/{lib,data_structures}.rs, folding/src/lib.rs:11-206.

@@ -193,6 +193,10 @@ def _load() -> ctypes.CDLL:
         "rsv_witness_program_create": (ctypes.c_int, [_u32p, sz, _u32p, sz, ctypes.c_uint32, ctypes.POINTER(WitnessShape), ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_void_p)]),
         "rsv_witness_program_destroy": (None, [vp]),
+        "rsv_witness_program_build": (ctypes.c_int, [_u8p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
+                                                     ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+        "rsv_witness_program_info": (ctypes.c_int, [vp, _u32p, _u32p, ctypes.POINTER(WitnessShape)]),
+        "rsv_witness_program_export": (ctypes.c_int, [vp, _u32p, _u32p, _u32p]),
         "rsv_witness_scratch_bytes": (ctypes.c_int, [vp, sz, ctypes.POINTER(sz)]),
         "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp, vp, vp]),
         "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u32p, _u8p,
@@ -214,6 +218,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
            "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
            "rsv_transcript_batch", "rsv_poseidon_flow_count", "rsv_witness_program_create", "rsv_witness_program_destroy",
+           "rsv_witness_program_build", "rsv_witness_program_info", "rsv_witness_program_export",
            "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval"]
 
 
@@ -517,21 +522,57 @@ def hints(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inner: i
 
 
 class WitnessProgram:
-    """A witness program resident on the device (rsv_witness_program): build one per proof shape with
-    circuit.build_program (or load a saved circuit.program.Program) and evaluate it for batches of that shape."""
+    """A witness program resident on the device (rsv_witness_program).  WitnessProgram.build(proof, cfg, ...) runs the
+    library's mirror of the reference's circuit gadgets over a template proof (rsv_witness_program_build);
+    WitnessProgram(program) loads arrays made earlier (witness_program.Program, e.g. from a file)."""
 
-    def __init__(self, program, device: int = 0):
-        self.program = program
-        self.n_vars = program.n_vars
-        sh = program.shape
-        self.shape = WitnessShape(sh["lp"], sh["lq"], sh["pow_bits"], sh["blowup"], sh["log_last"], sh["nq"], sh["n_inner"], sh["flow_count"],
-                                  sh["copies"])
-        instr = np.ascontiguousarray(program.instr, dtype=np.uint32)
-        levels = np.ascontiguousarray(program.level_offsets, dtype=np.uint32)
+    def __init__(self, program=None, device: int = 0, _handle=None):
+        self._h = None
+        if _handle is not None:
+            self._h = _handle
+        else:
+            sh = program.shape
+            shape = WitnessShape(sh["lp"], sh["lq"], sh["pow_bits"], sh["blowup"], sh["log_last"], sh["nq"], sh["n_inner"], sh["flow_count"],
+                                 sh["copies"])
+            instr = np.ascontiguousarray(program.instr, dtype=np.uint32)
+            levels = np.ascontiguousarray(program.level_offsets, dtype=np.uint32)
+            h = ctypes.c_void_p()
+            _check(lib.rsv_witness_program_create(instr.ctypes.data_as(_u32p), instr.shape[0], levels.ctypes.data_as(_u32p), len(levels) - 1,
+                                                  program.n_vars, ctypes.byref(shape), device, ctypes.byref(h)), "rsv_witness_program_create")
+            self._h = h
+            self._flow_wires = program.flow_wires
+        n_vars, n_levels = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self.shape = WitnessShape()
+        _check(lib.rsv_witness_program_info(self._h, ctypes.byref(n_vars), ctypes.byref(n_levels), ctypes.byref(self.shape)),
+               "rsv_witness_program_info")
+        self.n_vars, self.n_levels = int(n_vars.value), int(n_levels.value)
+
+    @classmethod
+    def build(cls, proof: bytes, cfg, inputs=STANDARD_INPUTS, copies: int = 1, device: int = 0) -> "WitnessProgram":
+        b = np.frombuffer(proof, dtype=np.uint8)
+        c = PcsConfig(cfg.pow_bits, cfg.log_blowup_factor, cfg.log_last_layer_degree_bound, cfg.n_queries)
+        pi = make_inputs(inputs)
         h = ctypes.c_void_p()
-        _check(lib.rsv_witness_program_create(instr.ctypes.data_as(_u32p), instr.shape[0], levels.ctypes.data_as(_u32p), len(levels) - 1,
-                                              program.n_vars, ctypes.byref(self.shape), device, ctypes.byref(h)), "rsv_witness_program_create")
-        self._h = h
+        _check(lib.rsv_witness_program_build(b.ctypes.data_as(_u8p), len(proof), ctypes.byref(c), pi, len(list(inputs)), copies, device,
+                                             ctypes.byref(h)), "rsv_witness_program_build")
+        return cls(_handle=h)
+
+    def export(self):
+        """-> witness_program.Program (instr, level_offsets, shape, flow_wires): what save / save_raw write and __init__ takes back."""
+        instr = np.zeros((self.n_vars, 8), np.uint32)
+        levels = np.zeros(self.n_levels + 1, np.uint32)
+        s = self.shape
+        wires = getattr(self, "_flow_wires", None)
+        if wires is None:
+            wires = np.zeros((s.copies * s.flow_count, 5), np.uint32)
+            _check(lib.rsv_witness_program_export(self._h, instr.ctypes.data_as(_u32p), levels.ctypes.data_as(_u32p), wires.ctypes.data_as(_u32p)),
+                   "rsv_witness_program_export")
+        else:
+            _check(lib.rsv_witness_program_export(self._h, instr.ctypes.data_as(_u32p), levels.ctypes.data_as(_u32p), None),
+                   "rsv_witness_program_export")
+        shape = dict(zip(witness_program.SHAPE_KEYS, (s.log_size_plonk, s.log_size_poseidon, s.pow_bits, s.log_blowup, s.log_last, s.n_queries,
+                                              s.n_inner, s.flow_count, s.copies)))
+        return witness_program.Program(instr, levels, self.n_vars, shape, wires)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -757,4 +798,4 @@ class Context:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
 
-from . import circuit  # noqa: E402,F401  (host side of rsv_witness_eval_dev: the recursion circuit -> witness program)
+from . import witness_program  # noqa: E402,F401  (the witness program container)

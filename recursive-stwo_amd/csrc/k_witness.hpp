@@ -1,7 +1,7 @@
 // k_witness.hpp — the recursion circuit's `variables` vector for a batch of proofs of one shape (rsv_witness_eval_dev).
 // The reference fills the vector while it runs the circuit's gadgets on ONE proof
 // (constraint_system/src/plonk_with_poseidon.rs:140-283).  Which gate or hint produces variable k is the same for every
-// proof of a shape, so the host writes that down once as a program (recursive-stwo_amd/circuit/program.py: one
+// proof of a shape, so the host writes that down once as a program (rsv_witness_program_build, circuit_builder.inc: one
 // instruction per variable, sorted by dependency depth) and this kernel evaluates one LEVEL of it per launch over
 // (instructions of the level) x (proofs).  Variables live in HBM as vars[variable][proof] (QM31 = 16 B), so a wave reads
 // and writes 1 KB rows; the work is HBM streaming (3 x 16 B per instruction and proof), not arithmetic.

@@ -411,9 +411,10 @@ struct PoseidonFlow {
 };
 
 // The circuit's `variables: Vec<QM31>` (constraint_system/src/plonk_with_poseidon.rs:19) for batches of proofs of one
-// shape: a witness program (include/rsv.h; built per shape by recursive-stwo_amd/circuit, stored with Program.save_raw)
-// loaded from a file and evaluated on the GPU.  variables(proofs)[i] is what PlonkWithPoseidonConstraintSystem holds after
-// the loop body of examples/multi-proofs/src/main.rs:66-139 ran `copies` times on proof i.
+// shape: a witness program (include/rsv.h) built from a template proof — the library runs its mirror of the gadgets over
+// it once — or loaded from a file, and evaluated on the GPU.  variables(proofs)[i] is what
+// PlonkWithPoseidonConstraintSystem holds after the loop body of examples/multi-proofs/src/main.rs:66-139 ran `copies`
+// times on proof i.
 struct WitnessProgram {
     rsv_witness_program* handle = nullptr;
     rsv_witness_shape shape{};
@@ -427,6 +428,34 @@ struct WitnessProgram {
 
     // PoseidonEntry::wire of r1..r4 and SwapOption::addr of every invocation of every copy (shape constants)
     std::vector<std::array<uint32_t, 5>> flow_wires;
+
+    // `multipliers` copies of the verifier of proofs shaped like `template_proof` (which must verify under config / inputs)
+    static WitnessProgram build(const std::vector<uint8_t>& template_proof, const PcsConfig& config, const Inputs& inputs, uint32_t multipliers = 1) {
+        WitnessProgram p;
+        const rsv_pcs_config abi_cfg = config.abi();
+        auto pi = abi_inputs(inputs);
+        check(rsv_witness_program_build(template_proof.data(), template_proof.size(), &abi_cfg, pi.data(), pi.size(), multipliers, default_device(),
+                                        &p.handle), "rsv_witness_program_build");
+        check(rsv_witness_program_info(p.handle, &p.n_vars, nullptr, &p.shape), "rsv_witness_program_info");
+        p.flow_wires.resize((size_t)p.shape.copies * p.shape.flow_count);
+        check(rsv_witness_program_export(p.handle, nullptr, nullptr, &p.flow_wires[0][0]), "rsv_witness_program_export");
+        return p;
+    }
+    void save(const std::string& path) const {
+        uint32_t n_levels = 0;
+        check(rsv_witness_program_info(handle, nullptr, &n_levels, nullptr), "rsv_witness_program_info");
+        std::vector<uint32_t> instr((size_t)n_vars * 8), levels(n_levels + 1);
+        check(rsv_witness_program_export(handle, instr.data(), levels.data(), nullptr), "rsv_witness_program_export");
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write witness program " + path);
+        const uint32_t head[4] = {0x57565352u, 1, n_vars, n_levels};
+        std::fwrite(head, 4, 4, f);
+        std::fwrite(&shape, 4, 9, f);
+        std::fwrite(levels.data(), 4, levels.size(), f);
+        std::fwrite(instr.data(), 4, instr.size(), f);
+        std::fwrite(flow_wires.data(), 4, flow_wires.size() * 5, f);
+        std::fclose(f);
+    }
 
     // file = "RSVW" | version 1 | n_vars | n_levels | rsv_witness_shape (9 words) | level_offsets[n_levels + 1] | instr[n_vars][8]
     //        | flow_wires[copies * flow_count][5]

@@ -201,7 +201,7 @@ static void test_poseidon_flow(const std::vector<uint8_t>& small, const std::vec
 }
 
 // The circuit's `variables` for a batch: the program file is written by the Python side of the host layer
-// (recursive-stwo_amd/circuit, Program.save_raw) for the shape of level10-1.bin; level11-1.bin is another proof of that
+// (WitnessProgram.build(...).export().save_raw) for the shape of level10-1.bin; level11-1.bin is another proof of that
 // shape, level12-1.bin is not.  What the reference's check_arithmetics looks at first — the four fixed variables 0, 1, i, j
 // (plonk_with_poseidon.rs:61-64) — and the statement words the proof allocation pushes next (data_structures/src/lib.rs:36-46).
 static void test_witness(const std::string& program_path, const std::vector<uint8_t>& l10, const std::vector<uint8_t>& l11,
@@ -231,6 +231,17 @@ static void test_witness(const std::string& program_path, const std::vector<uint
         EXPECT((vars[k][at + 2] == QM31{w[2], w[3], w[4], w[5]}) && (vars[k][at + 3] == QM31{w[6], w[7], w[8], w[9]}));
     }
     printf("witness: %u variables per proof, accept = %d %d %d %d\n", prog.n_vars, accept[0], accept[1], accept[2], accept[3]);
+    // built here from level11-1.bin as the template: the same program (it depends on the shape only), so the same vectors;
+    // and it survives a round trip through a file
+    WitnessProgram built = WitnessProgram::build(l11, prog.config(), inputs);
+    EXPECT(built.n_vars == prog.n_vars && built.flow_wires == prog.flow_wires);
+    std::vector<uint8_t> a2, r2;
+    auto vars2 = built.variables({l10, l11}, inputs, a2, r2);
+    EXPECT(vars2[0] == vars[0] && vars2[1] == vars[1]);
+    built.save(program_path + ".copy");
+    WitnessProgram again = WitnessProgram::load(program_path + ".copy");
+    auto vars3 = again.variables({l11}, inputs, a2, r2);
+    EXPECT(a2[0] == 1 && vars3[0] == vars[1]);
 }
 
 int main(int argc, char** argv) {

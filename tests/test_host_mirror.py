@@ -27,10 +27,10 @@ def test_host_mirror_runs_reference_tests(tmp_path):
     import rsvload
     from tests.conftest import fixture_cfg, read_proof
     rsv = rsvload.load_package()
-    prog = rsv.circuit.build_program(rsv, read_proof("level10-1.bin"), fixture_cfg("level10-1.bin"))
+    prog = rsv.WitnessProgram.build(read_proof("level10-1.bin"), fixture_cfg("level10-1.bin")).export()
     path = os.path.join(str(tmp_path), "level10.rsvw")
     prog.save_raw(path)
-    back = rsv.circuit.Program.load_raw(path)
+    back = rsv.witness_program.Program.load_raw(path)
     assert back.n_vars == prog.n_vars and back.shape == prog.shape and (back.instr == prog.instr).all()
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "proofs"), path], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr

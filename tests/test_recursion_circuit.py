@@ -1,5 +1,5 @@
-"""The recursion circuit (recursive-stwo_amd/circuit: constraint system, gadgets, the five verifier stages, witness
-program) against the reference's own fixtures — CPU only.
+"""The oracle's restatement of the recursion circuit (oracle/recursion_circuit: constraint system, gadgets, the five verifier
+stages, witness program) against the reference's own fixtures — CPU only.
 
 Each fixture of the reference's chain is the proof of the circuit that verifies the previous one
 (examples/single-proof/src/main.rs, examples/multi-proofs/src/main.rs:173-295).  So the circuit restated here, run on
@@ -10,7 +10,7 @@ fixture K with the CPU oracle's hints, must BE what fixture K+1 proves:
     multiplicities; the `variables` vector read through the wires), 40 + 48 of the Poseidon component (the PoseidonFlow)
     — evaluated at K+1's OODS point is the sampled value K+1 carries for that column: 110 QM31 equalities per pair.
 tools/pin_recursion_circuit.py checks all 14 pairs and records them in tests/golden/recursion_circuit_pins.json together
-with the one thing that has to be searched (the order in which the reference walked two HashSets, see circuit/verifier.py);
+with the one thing that has to be searched (the order in which the reference walked two HashSets, see oracle/recursion_circuit/verifier.py);
 here a subset is re-checked from that file.  The same run also cross-checks the two restatements of the circuit's Poseidon
 invocations: cs.flow must equal the C oracle's rsvo_poseidon_flow record for record.
 """
@@ -126,7 +126,7 @@ def test_program_files_round_trip(tmp_path):
 def test_program_depends_on_the_shape_only():
     """level10-1 and level11-1 are two different proofs of one shape: the programs extracted from them are identical, so a
     program built from one template serves every proof of its shape — also where the reference's own gate list follows the
-    witness (the `op` of CirclePointM31Var::select, circuit/gadgets.py)."""
+    witness (the `op` of CirclePointM31Var::select, gadgets.pm_select)."""
     p10, _, _ = _program_for("level10-1.bin")
     p11, _, _ = _program_for("level11-1.bin")
     assert p10.n_vars == p11.n_vars and p10.shape == p11.shape

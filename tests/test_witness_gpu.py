@@ -1,7 +1,8 @@
-"""rsv_witness_eval (`-m gpu`): the recursion circuit's `variables` vector, evaluated on the GPU for a batch, against the
-values the circuit's gadgets compute when they are run — proof by proof, Python integers, CPU oracle's hints — on the
-same proofs (oracle/recursion_circuit.build_circuit; that code is pinned to the reference's fixtures by
-tests/test_recursion_circuit.py).  Program built on the GPU box from the GPU's own hints of a template proof."""
+"""rsv_witness_program_build + rsv_witness_eval (`-m gpu`): the library's own mirror of the circuit's gadgets (C++, fed with
+the GPU's hints of a template proof) must write the program the CPU oracle's restatement of the circuit derives, byte for
+byte; and the recursion circuit's `variables` vector, evaluated on the GPU for a batch, must equal the values the oracle's
+gadgets compute when they are run — proof by proof, Python integers, CPU oracle's hints — on the same proofs
+(oracle/recursion_circuit, itself pinned to the reference's fixtures by tests/test_recursion_circuit.py)."""
 import numpy as np
 import pytest
 
@@ -32,13 +33,14 @@ def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
     the rows of the two valid proofs of the shape equal the gadgets' `variables`, the tampered and the foreign proof are
     flagged; the program equals the one extracted from the oracle's run (same instructions, same levels)."""
     cfg = fixture_cfg(template)
-    prog = rsv.circuit.build_program(rsv, read_proof(template), cfg, _inputs(template))
+    wp = rsv.WitnessProgram.build(read_proof(template), cfg, _inputs(template))
+    prog = wp.export()
     want_t, c, d = _oracle_variables(template)
     want_o, c_other, _ = _oracle_variables(other)
     from oracle import recursion_circuit as rc
     ref = rc.program.extract(c, d)
-    assert prog.n_vars == ref.n_vars and np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.level_offsets, ref.level_offsets)
-    wp = rsv.WitnessProgram(prog)
+    assert prog.n_vars == ref.n_vars and prog.shape == ref.shape
+    assert np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.level_offsets, ref.level_offsets) and np.array_equal(prog.flow_wires, ref.flow_wires)
     foreign = "level12-1.bin" if template != "level12-1.bin" else "level9-1.bin"
     batch = [read_proof(template), read_proof(other), ob.tamper(read_proof(template), 7), read_proof(foreign), read_proof(other)]
     variables, accept, reason, flow, swap = rsv.witness(batch, wp, _inputs(template), with_flow=True)
@@ -50,7 +52,7 @@ def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
     assert np.array_equal(flow[1], want_flow[:, :32]) and np.array_equal(swap[1], want_flow[:, 32].astype(np.uint8))
     at = np.empty(prog.n_vars, np.int64)
     at[prog.instr[:, 1]] = np.arange(prog.n_vars)
-    P_ = rsv.circuit.program
+    P_ = rsv.witness_program
     checked = 0
     for k in range(0, prog.shape["flow_count"], 7):
         for j in range(4):
@@ -76,9 +78,11 @@ def test_witness_of_five_copies_in_one_circuit(rsv):
     """examples/multi-proofs verifies recursive_proof_16_15.bin five times in one circuit (main.rs:64, 173-196):
     the program of that circuit (about 330 000 variables; its 291 870 Plonk rows are the level1 fixture's 2^19)."""
     name = "recursive_proof_16_15.bin"
-    prog = rsv.circuit.build_program(rsv, read_proof(name), fixture_cfg(name), _inputs(name), copies=5)
-    want, _, _ = _oracle_variables(name, 5)
-    wp = rsv.WitnessProgram(prog)
+    wp = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name), copies=5)
+    want, c, d = _oracle_variables(name, 5)
+    from oracle import recursion_circuit as rc
+    prog, ref = wp.export(), rc.program.extract(c, d, 5)
+    assert np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.flow_wires, ref.flow_wires) and prog.shape["copies"] == 5
     variables, accept, _ = rsv.witness([read_proof(name)] * 3, wp, _inputs(name))
     assert accept.tolist() == [1, 1, 1]
     for k in range(3):
@@ -86,14 +90,27 @@ def test_witness_of_five_copies_in_one_circuit(rsv):
     wp.close()
 
 
+def test_build_refuses_what_is_not_a_template(rsv):
+    """A template has to verify under the given configuration and inputs; anything else is an error code, not a program."""
+    name = "level12-1.bin"
+    proof = read_proof(name)
+    for bad_proof, cfg, inputs, code in ((ob.tamper(proof, 5), fixture_cfg(name), _inputs(name), -5), (proof, fixture_cfg("level9-1.bin"), _inputs(name), -2),
+                                         (proof, fixture_cfg(name), [(1, (1, 0, 0, 0))], -5), (proof[:4000], fixture_cfg(name), _inputs(name), -2)):
+        with pytest.raises(rsv.RsvError) as e:
+            rsv.WitnessProgram.build(bad_proof, cfg, inputs)
+        assert e.value.code == code
+
+
 def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
     """Context.witness on tensors in HBM (n = 96 copies, two calls on one context: the second reuses the scratch), and the
     API errors: a configuration that is not the program's, a misaligned output."""
     import torch
     name = "level12-1.bin"
-    prog = rsv.circuit.build_program(rsv, read_proof(name), fixture_cfg(name), _inputs(name))
+    built = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name))
+    prog = built.export()
     want, _, _ = _oracle_variables(name)
-    wp = rsv.WitnessProgram(prog)
+    wp = rsv.WitnessProgram(prog)  # the same program through rsv_witness_program_create, as a host that loads a file would
+    built.close()
     n = 96
     blob, offsets = rsv.pack([read_proof(name)] * n)
     dev = torch.device("cuda:0")

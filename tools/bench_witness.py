@@ -40,10 +40,10 @@ def main():
     cfg = rsv.PcsConfig(e["pow_bits"], e["log_blowup_factor"], e["log_last_layer_degree_bound"], e["n_queries"])
     proof = bench.read_fixture(args.fixture)
     t0 = time.perf_counter()
-    prog = rsv.circuit.build_program(rsv, proof, cfg, inputs, copies=args.copies)
+    wp = rsv.WitnessProgram.build(proof, cfg, inputs, copies=args.copies)
     build_s = time.perf_counter() - t0
-    wp = rsv.WitnessProgram(prog)
-    P_ = rsv.circuit.program
+    prog = wp.export()
+    P_ = rsv.witness_program
     ops = prog.instr[:, 0]
     n_two = int(np.isin(ops, (P_.ADD, P_.MUL)).sum())
     n_one = int(np.isin(ops, (P_.MULC, P_.COPY, P_.INV, P_.INV0, P_.QINV, P_.CINV, P_.COORD, P_.BIT)).sum())
