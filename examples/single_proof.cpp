@@ -41,6 +41,13 @@ int main(int argc, char** argv) {
         flow.check_poseidon_invocations();
         printf("Poseidon circuit size: %zu invocations -> log_size_poseidon %u of the next level's proof\n", flow.invocations.size(),
                flow.log_size_poseidon());
+        // what the reference hands to the prover next (:90-98): cs.variables — here from the GPU, through the witness
+        // program of this proof's shape (the proof itself serves as the template)
+        WitnessProgram program = WitnessProgram::build(proof, config, inputs);
+        std::vector<uint8_t> accept, reason;
+        auto variables = program.variables({proof}, inputs, accept, reason);
+        printf("Plonk circuit: %zu variables (the first witnesses: log sizes %u / %u), %zu flow entries with wires\n", variables[0].size(),
+               variables[0][4][0], variables[0][5][0], program.flow_wires.size());
     } catch (const VerificationError& e) {
         printf("proof rejected: %s\n", e.what());
         return 1;

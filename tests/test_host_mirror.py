@@ -59,6 +59,8 @@ def test_examples_run(tmp_path):
     # the recursion circuit of examples/single-proof verifies small_proof.bin once: 3 481 Poseidon invocations, which pad
     # to the 2^15 Poseidon rows in the header of the proof it writes (recursive_proof_16_15.bin)
     assert "3481 invocations -> log_size_poseidon 15" in out.stdout, out.stdout
+    # and its Plonk half: the 52 113 variables behind the 45 870 rows that pad to the 2^16 of that header
+    assert "Plonk circuit: 52113 variables (the first witnesses: log sizes 4 / 8), 3481 flow entries with wires" in out.stdout, out.stdout
     files = [os.path.join(proofs, f) for f in ("level1-5.bin", "level7-1.bin", "level13-1.bin", "hybrid_hash.bin")]
     out = subprocess.run([_build_example(tmp_path, "multi_proofs")] + files, capture_output=True, text=True)
     lines = out.stdout.strip().splitlines()
