@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="experiments only: a tuning knob of the library (rsv_ctx_set_option, names in rsv.OPTIONS), e.g. "
                          "critical_chain=off.  The bench line is measured with none.")
+    ap.add_argument("--witness-proofs", type=int, default=1024,
+                    help="side leg: the recursion circuit's witness for this many proofs of the level10 shape (0 = skip; skipped with --perm-log2 0)")
     ap.add_argument("--emit-flow", action="store_true",
                     help="also emit the PoseidonFlow of every proof's verification circuit (SURVEY 8f.1, second half: 128 B + "
                          "1 B per Poseidon invocation, ~0.7 MB per standard proof) from the verifying pass; any workload")
@@ -443,14 +445,14 @@ def main():
     # SURVEY §8f.1 widening: the recursion circuit's `variables` for a batch (rsv_witness_eval_dev): 1 024 proofs of the
     # level10 shape, program built here from the GPU's own hints of the fixture; HBM streaming
     witness = None
-    if args.perm_log2 > 0 and world == 1 and rank == 0:
+    if args.perm_log2 > 0 and args.witness_proofs > 0 and world == 1 and rank == 0:
         wname = "level10-1.bin"
         wproof = read_fixture(wname)
         wcfg = fixture_configs(rsv, [wname])[0]
         t1 = time.perf_counter()
         wp = rsv.WitnessProgram.build(wproof, wcfg, device=dev_index)
         wbuild = time.perf_counter() - t1
-        wn = 1024
+        wn = args.witness_proofs
         wblob, woff = rsv.pack([wproof] * wn)
         d_wblob, d_woff = torch.from_numpy(wblob.copy()).to(dev), torch.from_numpy(woff.astype(np.int64)).to(dev)
         d_wvars = torch.empty((wn, wp.n_vars, 4), dtype=torch.int32, device=dev)

@@ -81,6 +81,8 @@ def main():
                                               round(c.get("SQ_ACTIVE_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
                                               round(c.get("SQ_INSTS_VALU", 0) * 3.440 / (ms * 1e-3 * 1024 * 2.4e9), 3) if ms > 0 else 0]) + "\n")
             short = k.replace("rsv::", "").split("<")[0]
+            if short in latest["kernels"] and " true" in k:
+                continue  # a FLOW / side instantiation of a template kernel never replaces the verdict instantiation
             latest["kernels"][short] = {"avg_ms": ms, "hbm_bytes_corrected": int((2 * fetch + write) * 1024),
                                         "SQ_INSTS_VALU": int(c.get("SQ_INSTS_VALU", 0)), "eff_clock_GHz": round(clock, 3)}
     with open(os.path.join(dst, "pmc_latest.json"), "w") as f:
