@@ -502,6 +502,18 @@ def main():
                      "note": "rsv_verify_batch_host on the cpu_baseline sample: proofs start in pageable host memory, one "
                              "buffer each; includes the gather into pinned memory and the PCIe upload.  Never `value`."}
         cpu = cpu_baseline(blob_host, offs_host, n_s, table, of, fixtures)
+        if witness is not None:
+            # the witness leg's CPU baseline: the oracle's restatement of the circuit (Python integers) on ONE proof, one thread
+            from tests import oracle_binding as ob
+            from oracle import recursion_circuit as rc
+            t1 = time.perf_counter()
+            c_or, _, _ = rc.build_circuit(read_fixture(witness["fixture"]), ob)
+            odt = time.perf_counter() - t1
+            if len(c_or.variables) != witness["variables_per_proof"]:
+                raise SystemExit("witness leg: the oracle's circuit has another number of variables")
+            witness["cpu_baseline"] = {"value": 1.0 / odt, "unit": "proofs/s", "cores": 1, "kind": "port",
+                                       "sample": "one proof: oracle/recursion_circuit (the gadgets run in Python integers on the C "
+                                                 "oracle's hints) — a restatement for checking, not a tuned implementation"}
         if valu is not None and cpu.get("perms_per_proof"):
             # useful permutations (the oracle's batched-walk count) the whole pipeline retires per second and GPU, against
             # the instruction-cost ceiling of the bare permutation: the efficiency figure of this VALU-bound path

@@ -8,7 +8,7 @@
                                    value of a column's interpolant at a point
 What pins it to the reference: every fixture is the proof of the circuit that verifies the previous one, so the columns of
 the circuit restated for fixture K, evaluated at fixture K+1's OODS point, must be K+1's sampled values — and are, all 110,
-for all 14 consecutive pairs (tests/test_recursion_circuit.py, tools/pin_recursion_circuit.py).
+for all 14 consecutive pairs (tests/test_recursion_circuit.py, tests/pin_recursion_circuit.py).
 What it checks: the library's own builder (C++, rsv_witness_program_build) must produce this package's program byte for
 byte, and the GPU's evaluation must produce this package's `variables` (tests/test_witness_gpu.py).
 Only tests/ and the parity tooling import this package."""

@@ -114,7 +114,7 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
         man = {e["file"]: e for e in json.load(f)["proofs"]}
     rcs = round_constants()
-    out = {"_about": "written by tools/pin_recursion_circuit.py: per fixture pair, the HashSet walk orders under which the restated "
+    out = {"_about": "written by tests/pin_recursion_circuit.py: per fixture pair, the HashSet walk orders under which the restated "
                      "circuit reproduces every sampled value of the next fixture's Plonk (22) and Poseidon (88) columns",
            "pairs": []}
     for src, mult, dst in CHAIN:

@@ -63,6 +63,7 @@ def test_bench_single_gpu_line():
     assert e["bound"] == "hbm" and 0 < e["frac"] <= 1.0 and e["algorithmic_bytes_per_perm"] == 65 + 416 * 16
     w = d["recursion_circuit_witness"]
     assert w["proofs"] == 1024 and w["variables_per_proof"] == 47788 and w["levels"] > 100 and w["proofs_per_s"] > 1e4
+    assert w["cpu_baseline"]["kind"] == "port" and 0 < w["cpu_baseline"]["value"] < w["proofs_per_s"]
 
 
 @pytest.mark.gpu

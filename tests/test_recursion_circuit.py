@@ -9,7 +9,7 @@ fixture K with the CPU oracle's hints, must BE what fixture K+1 proves:
   * the interpolant of each of its columns — 10 preprocessed + 12 trace columns of the Plonk component (wires, op,
     multiplicities; the `variables` vector read through the wires), 40 + 48 of the Poseidon component (the PoseidonFlow)
     — evaluated at K+1's OODS point is the sampled value K+1 carries for that column: 110 QM31 equalities per pair.
-tools/pin_recursion_circuit.py checks all 14 pairs and records them in tests/golden/recursion_circuit_pins.json together
+tests/pin_recursion_circuit.py checks all 14 pairs and records them in tests/golden/recursion_circuit_pins.json together
 with the one thing that has to be searched (the order in which the reference walked two HashSets, see oracle/recursion_circuit/verifier.py);
 here a subset is re-checked from that file.  The same run also cross-checks the two restatements of the circuit's Poseidon
 invocations: cs.flow must equal the C oracle's rsvo_poseidon_flow record for record.

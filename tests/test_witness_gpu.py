@@ -74,6 +74,34 @@ def test_witness_of_a_batch_matches_the_gadgets(rsv, template, other):
     wp.close()
 
 
+def test_builder_writes_the_oracles_program_for_every_fixture_shape(rsv, manifest):
+    """rsv_witness_program_build (the library's C++ mirror of the gadgets, GPU hints) against the oracle's Python restatement
+    (CPU oracle's hints) on every Poseidon-channel fixture of the reference — 15 proofs, 11 distinct shapes, n_queries 8 … 80,
+    last layers of 4 … 256 coefficients, one and three public inputs: the same instructions in the same levels and the same
+    flow wires, byte for byte; and each program evaluates its own template to the oracle's `variables`."""
+    from oracle import recursion_circuit as rc
+    seen = set()
+    for e in manifest:
+        if e.get("expect") != "ok" or "struct" in e:
+            continue
+        name = e["file"]
+        proof, inputs = read_proof(name), _inputs(name)
+        wp = rsv.WitnessProgram.build(proof, fixture_cfg(name), inputs)
+        prog = wp.export()
+        c, d, _ = rc.build_circuit(proof, ob, inputs)
+        ref = rc.program.extract(c, d)
+        assert prog.shape == ref.shape and prog.n_vars == ref.n_vars, name
+        assert np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.level_offsets, ref.level_offsets), name
+        assert np.array_equal(prog.flow_wires, ref.flow_wires), name
+        key = tuple(sorted(prog.shape.items()))
+        if key not in seen:  # one evaluation per shape
+            seen.add(key)
+            variables, accept, _ = rsv.witness([proof], wp, inputs)
+            assert accept[0] == 1 and np.array_equal(variables[0], np.array(c.variables, dtype=np.uint32)), name
+        wp.close()
+    assert len(seen) >= 10
+
+
 def test_witness_of_five_copies_in_one_circuit(rsv):
     """examples/multi-proofs verifies recursive_proof_16_15.bin five times in one circuit (main.rs:64, 173-196):
     the program of that circuit (about 330 000 variables; its 291 870 Plonk rows are the level1 fixture's 2^19)."""
