@@ -125,10 +125,14 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
 // commitments, last-layer polynomial, proof of work, queries) needs the section offsets the parser found.  The digest
 // travels from one to the other through ProofCtx::pow_digest.  A small batch's step is a chain of dependent kernels,
 // and this takes the parser (0.1 ms for 1 024 proofs: ~45 dependent HBM round trips) off that chain.
-template <int PHASE>
+// FLOW (PHASE 0 only): the row also writes the PoseidonFlow records of the channel operations, as k_transcript<true> does
+// — every lane its own word of the input and of the output state (64 + 64 contiguous bytes per record) — so that a small
+// batch's flow does not wait for the 3 ms lane-form chain.
+template <int PHASE, bool FLOW = false>
 __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                         uint32_t n, const ProofMeta* __restrict__ metas,
-                                                        ProofCtx* __restrict__ ctxs) {
+                                                        ProofCtx* __restrict__ ctxs, FlowArgs fa) {
+    static_assert(!FLOW || PHASE == 0, "the PoseidonFlow records are written by the unsplit kernel");
     const uint32_t i = threadIdx.x & 15u;
     const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (p >= n) return;  // whole rows leave together (DPP needs every lane of a live row)
@@ -144,15 +148,39 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     const bool rate = i < 8;
     const RowRC rc = load_row_rc(i);
     uint32_t dg = 0, n_sent = 0;
+    uint32_t* frec = nullptr;  // FLOW: this proof's records, word-addressed (nullptr: none)
+    uint32_t fidx = 0;
+    if (FLOW) {
+        const uint32_t total = flow_total(m.nq, m.n_inner, m.last_n, m.A, m.B, m.M);
+        const bool fits = total <= fa.stride;
+        if (i == 0) {
+            c.flow_on = fits ? 1u : 0u;
+            if (fa.count) fa.count[p] = fits ? total : 0u;
+        }
+        if (fits) frec = fa.rec + (size_t)p * fa.stride * FLOW_WORDS;
+    }
+    // record of one channel operation: lane i holds word i of the input (left || right = rate || digest half) and of the output
+    auto record = [&](uint32_t in, uint32_t out) {
+        if (FLOW && frec) {
+            frec[(size_t)fidx * FLOW_WORDS + i] = in;
+            frec[(size_t)fidx * FLOW_WORDS + 16 + i] = out;
+            if (i == 0) fa.swap[(size_t)p * fa.stride + fidx] = 0;
+            fidx++;
+        }
+    };
     // mix: digest = perm(left || digest)[8..16]
     auto mix = [&](uint32_t left_word) {
-        uint32_t out = poseidon2_row(rate ? left_word : dg, i, rc);
+        const uint32_t in = rate ? left_word : dg;
+        uint32_t out = poseidon2_row(in, i, rc);
+        record(in, out);
         if (!rate) dg = out;
         n_sent = 0;
     };
     // draw: perm([n_sent, 0 x 7] || digest)[0..8]; the digest is not advanced
     auto draw = [&]() {
-        uint32_t out = poseidon2_row(rate ? (i == 0 ? n_sent : 0u) : dg, i, rc);
+        const uint32_t in = rate ? (i == 0 ? n_sent : 0u) : dg;
+        uint32_t out = poseidon2_row(in, i, rc);
+        record(in, out);
         n_sent++;
         return out;
     };
@@ -259,6 +287,8 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
         out = draw();
         if (rate && got + i < m.nq) c.raw_q[got + i] = out;
     }
+    if (FLOW)  // the circuit's surplus draws: same channel, no new value
+        for (uint32_t draws = (m.nq + 7u) / 8u; draws < (m.nq + 3u) / 4u; draws++) (void)draw();
 }
 
 }  // namespace rsv
