@@ -38,10 +38,8 @@ __device__ __forceinline__ QM31 q_of(uint4 v) { return q_mk(v.x, v.y, v.z, v.w);
 __device__ __forceinline__ uint4 u4_of(QM31 q) { return make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); }
 __device__ __forceinline__ uint4 u4_words(const uint32_t* w) { return make_uint4(w[0], w[1], w[2], w[3]); }
 
-__global__ __launch_bounds__(256) void k_witness_level(WitnessArgs a) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t i = a.begin + (uint32_t)(t / a.n), p = (uint32_t)(t % a.n);
-    if (i >= a.end) return;
+// one instruction for one proof
+__device__ __forceinline__ void witness_exec(const WitnessArgs& a, uint32_t i, uint32_t p) {
     const uint32_t* in = a.instr + (size_t)i * 8;
     const uint32_t op = in[0], dst = in[1], x = in[2], y = in[3], i0 = in[4], i1 = in[5], i2 = in[6];
     const size_t n = a.n;
@@ -98,6 +96,29 @@ __global__ __launch_bounds__(256) void k_witness_level(WitnessArgs a) {
     }
     }
     a.vars[dst * n + p] = r;
+}
+
+// one level, grid = (instructions of the level) x (proofs)
+__global__ __launch_bounds__(256) void k_witness_level(WitnessArgs a) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = a.begin + (uint32_t)(t / a.n), p = (uint32_t)(t % a.n);
+    if (i >= a.end) return;
+    witness_exec(a, i, p);
+}
+
+// The narrow tail of a program (the Poseidon AIR's accumulator chain: ~125 levels of 1 .. 28 instructions) in ONE launch:
+// dependencies never cross proofs, so a workgroup that owns 64 proofs can walk the levels on its own — its four waves
+// share a level's instructions, a workgroup barrier separates levels (the waves of a workgroup share the CU's L1, so what
+// one wave stored is what the next level's loads see).
+__global__ __launch_bounds__(256) void k_witness_strip(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t l0, uint32_t l1) {
+    const uint32_t p = blockIdx.x * 64 + (threadIdx.x & 63u), wv = threadIdx.x >> 6;
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t begin = level_offsets[l], end = level_offsets[l + 1];
+        if (p < a.n)
+            for (uint32_t i = begin + wv; i < end; i += 4) witness_exec(a, i, p);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // vars[variable][proof] -> out[proof][variable] (the reference's per-proof vector), 32 x 32 tiles through LDS
