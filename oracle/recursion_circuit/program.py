@@ -6,12 +6,20 @@ from __future__ import annotations
 
 import numpy as np
 
-import rsvload
-
-_w = rsvload.load_package().witness_program
-Program, SHAPE_KEYS, OP_NAMES, INSTR_WORDS = _w.Program, _w.SHAPE_KEYS, _w.OP_NAMES, _w.INSTR_WORDS
 (CONST, ADD, MUL, MULC, COPY, INV, INV0, QINV, CINV, COORD, BIT, FLOW, WORD, WORD4, FRI_COMMIT, LAST_POLY, NONCE, TRACE_COL,
  FRI_COL) = range(19)
+OP_NAMES = ("CONST ADD MUL MULC COPY INV INV0 QINV CINV COORD BIT FLOW WORD WORD4 FRI_COMMIT LAST_POLY NONCE TRACE_COL "
+            "FRI_COL").split()
+INSTR_WORDS = 8  # op, dst, a, b, imm0..imm3
+SHAPE_KEYS = ("lp", "lq", "pow_bits", "blowup", "log_last", "nq", "n_inner", "flow_count", "copies")
+
+
+class Program:
+    """instr uint32[n_vars, 8] sorted by level, level_offsets uint32[n_levels + 1], shape, flow_wires uint32[copies *
+    flow_count, 5] — the same fields as the product's container (recursive-stwo_amd/witness_program.py), nothing shared."""
+
+    def __init__(self, instr, level_offsets, n_vars, shape, flow_wires):
+        self.instr, self.level_offsets, self.n_vars, self.shape, self.flow_wires = instr, level_offsets, n_vars, shape, flow_wires
 
 W_LP, W_LQ, W_PLONK_SUM, W_POSEIDON_SUM, W_COMMIT0 = 0, 1, 2, 6, 17
 

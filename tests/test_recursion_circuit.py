@@ -109,9 +109,17 @@ def _program_for(name, copies=1):
     return rc.program.extract(c, d, copies), c, d
 
 
+def _product_program(prog):
+    """The oracle's program in the product's container (what rsv.WitnessProgram takes, and what it saves and loads)."""
+    import rsvload
+    return rsvload.load_package().witness_program.Program(prog.instr, prog.level_offsets, prog.n_vars, prog.shape, prog.flow_wires)
+
+
 def test_program_files_round_trip(tmp_path):
-    prog, _, _ = _program_for("level12-1.bin")
-    for save, load, name in ((prog.save, rc.program.Program.load, "p.npz"), (prog.save_raw, rc.program.Program.load_raw, "p.rsvw")):
+    import rsvload
+    P = rsvload.load_package().witness_program.Program
+    prog = _product_program(_program_for("level12-1.bin")[0])
+    for save, load, name in ((prog.save, P.load, "p.npz"), (prog.save_raw, P.load_raw, "p.rsvw")):
         path = str(tmp_path / name)
         save(path)
         back = load(path)
@@ -120,7 +128,7 @@ def test_program_files_round_trip(tmp_path):
     with open(str(tmp_path / "junk"), "wb") as f:
         f.write(b"\0" * 100)
     with pytest.raises(ValueError):
-        rc.program.Program.load_raw(str(tmp_path / "junk"))
+        P.load_raw(str(tmp_path / "junk"))
 
 
 def test_program_depends_on_the_shape_only():
@@ -187,7 +195,8 @@ def test_program_create_rejects_what_the_device_could_not_index():
 
     def create(instr, levels=None):
         try:
-            rsv.WitnessProgram(rc.program.Program(instr, prog.level_offsets if levels is None else levels, prog.n_vars, prog.shape))
+            rsv.WitnessProgram(rsv.witness_program.Program(instr, prog.level_offsets if levels is None else levels, prog.n_vars, prog.shape,
+                                                           prog.flow_wires))
         except rsv.RsvError as e:
             return e.code
         return 0
