@@ -95,17 +95,6 @@ def _coset_points(initial_index, step_index, log_size):
     return x, y
 
 
-def _q_scalar_mul(arr4, s):
-    """QM31 arrays (4 object arrays) times one QM31."""
-    a0, a1, a2, a3 = arr4
-    b0, b1, b2, b3 = s
-    ac0, ac1 = a0 * b0 - a1 * b1, a0 * b1 + a1 * b0
-    bd0, bd1 = a2 * b2 - a3 * b3, a2 * b3 + a3 * b2
-    ad0, ad1 = a0 * b2 - a1 * b3, a0 * b3 + a1 * b2
-    bc0, bc1 = a2 * b0 - a3 * b1, a2 * b1 + a3 * b0
-    return [(ac0 + 2 * bd0 - bd1) % P, (ac1 + 2 * bd1 + bd0) % P, (ad0 + bc0) % P, (ad1 + bc1) % P]
-
-
 class PointEvaluator:
     """f(point) for columns given on CanonicCoset(log_size).circle_domain() in bit-reversed order: the circle-to-line
     and line folds of the interpolant with the point's coordinates in the place of the folding randomness.  The weights
