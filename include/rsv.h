@@ -153,9 +153,12 @@ typedef enum rsv_option {
     RSV_OPT_CRITICAL_CHAIN = 13,  /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
     RSV_OPT_DEVICE_ORDER = 14,    /* 0 / 1 batches under one configuration: slot order by shape on the device, no host round
                                      trip inside the call; 2 the host-side bucketing of multi-configuration batches */
-    RSV_OPT_GRAPH = 15            /* 0 / 2 off; 1 (experiment) a call repeated with identical arguments — same buffers, sizes,
+    RSV_OPT_GRAPH = 15,           /* 0 / 2 off; 1 (experiment) a call repeated with identical arguments — same buffers, sizes,
                                      configuration, public inputs — is captured into a HIP graph on its second sighting
                                      and replayed afterwards; rsv_last_stage_times then reports the last plain call */
+    RSV_OPT_WITNESS_LAYOUT = 16   /* rsv_witness_eval_dev's d_variables: 0 / 1 [proof][variable] (the reference's vector per
+                                     proof); 2 [variable][proof] — what the level kernels write: no transpose (a third of
+                                     the traffic) and no second copy in scratch, for consumers that gather for many proofs */
 } rsv_option;
 int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 
@@ -480,7 +483,8 @@ int rsv_witness_program_export(const rsv_witness_program* prog, uint32_t* instr,
 /* HBM the context will hold for a batch of n proofs (hints of the verifying pass + variables[var][proof]). */
 int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t* bytes);
 /* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and
- * writes d_variables [n][n_vars][4]: row i = the `variables` vector of the circuit that verifies proof i.
+ * writes d_variables [n][n_vars][4]: row i = the `variables` vector of the circuit that verifies proof i
+ * ([n_vars][n][4] under RSV_OPT_WITNESS_LAYOUT = 2).
  * d_accept[i] = 1 iff proof i verified AND is of the program's shape; only those rows are defined (the others hold the
  * constants and zeros).  d_variables 16-byte aligned.
  * d_flow [n][flow_count][32] + d_flow_swap [n][flow_count] (optional, both or neither; as rsv_hints_out::d_flow with

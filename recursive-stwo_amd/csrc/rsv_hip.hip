@@ -44,6 +44,7 @@ struct Options {
     int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
     int device_order = 0;      // 0 / 1 single-configuration batches: slot order on the device, no host round trip; 2 host
     int graph = 0;             // 0 / 2 off, 1 replay repeated identical calls as a HIP graph (experiment)
+    int witness_layout = 0;    // 0 / 1 d_variables [proof][variable], 2 [variable][proof]
 };
 static Options g_default_options;
 static std::mutex g_options_mu;
@@ -227,6 +228,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_CRITICAL_CHAIN: return tri(&o.critical_chain);
         case RSV_OPT_DEVICE_ORDER: return tri(&o.device_order);
         case RSV_OPT_GRAPH: return tri(&o.graph);
+        case RSV_OPT_WITNESS_LAYOUT: return tri(&o.witness_layout);
         case RSV_OPT_WS_BUDGET_MB:
             if (value < 1 || value > (1ll << 20)) return RSV_E_RANGE;
             o.ws_budget_mb = value; return RSV_OK;

@@ -153,6 +153,14 @@ def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
         got = d_vars.cpu().numpy().view(np.uint32)
         assert d_acc.cpu().numpy().all() and all(np.array_equal(got[k], want) for k in (0, 1, n // 2, n - 1))
     assert wp.scratch_bytes(n) > n * prog.n_vars * 16
+    # the other output layout: [variable][proof], as the level kernels write it (no transpose, no second copy)
+    ctx.set_option("witness_layout", "by_variable")
+    d_byvar = torch.zeros((prog.n_vars, n, 4), dtype=torch.int32, device=dev)
+    ctx.witness(wp, d_blob, d_off, n, d_byvar, d_acc, inputs=_inputs(name))
+    ctx.synchronize()
+    byvar = d_byvar.cpu().numpy().view(np.uint32)
+    assert np.array_equal(byvar[:, 0], want) and np.array_equal(byvar[:, n - 1], want) and np.array_equal(byvar[:, 17], want)
+    ctx.set_option("witness_layout", "by_proof")
     other = rsv.WitnessProgram(prog)
     other.shape.n_queries = 9  # what cfg() reports to the call below
     with pytest.raises(rsv.RsvError) as e:

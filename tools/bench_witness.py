@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=1)
+    ap.add_argument("--layout", choices=["by_proof", "by_variable"], default="by_proof",
+                    help="by_variable: d_variables[variable][proof] as the level kernels write it (RSV_OPT_WITNESS_LAYOUT = 2): no transpose")
     args = ap.parse_args()
     import rsvload
     rsv = rsvload.load_package()
@@ -49,7 +51,7 @@ def main():
     n_one = int(np.isin(ops, (P_.MULC, P_.COPY, P_.INV, P_.INV0, P_.QINV, P_.CINV, P_.COORD, P_.BIT)).sum())
     n_h16 = int(np.isin(ops, (P_.FLOW, P_.WORD4, P_.FRI_COMMIT, P_.LAST_POLY, P_.FRI_COL)).sum())
     n_h4 = int(np.isin(ops, (P_.WORD, P_.NONCE, P_.TRACE_COL)).sum())
-    bytes_per_proof = 16 * prog.n_vars + 32 * n_two + 16 * n_one + 16 * n_h16 + 4 * n_h4 + 32 * prog.n_vars
+    bytes_per_proof = 16 * prog.n_vars + 32 * n_two + 16 * n_one + 16 * n_h16 + 4 * n_h4 + (32 * prog.n_vars if args.layout == "by_proof" else 0)
     n = args.proofs
     dev = torch.device("cuda:0")
     batch = [proof] * n
@@ -63,6 +65,7 @@ def main():
     d_vars = torch.empty((n, prog.n_vars, 4), dtype=torch.int32, device=dev)
     d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
     ctx = rsv.Context(0)
+    ctx.set_option("witness_layout", args.layout)
     s = prog.shape
     M = max(s["lp"] + 1, s["lq"] + 2) + s["blowup"]
     hint = dict(shape=(s["nq"], M, s["n_inner"]),
@@ -97,7 +100,7 @@ def main():
         "metric": "recursion_circuit_witnesses_per_s", "value": n / (whole_ms * 1e-3), "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": whole_ms, "higher_is_better": True, "dtype": "u32 (M31 / QM31)", "data": "synthetic",
         "config": {"workload": f"witness of the circuit verifying {args.fixture} x{args.copies}", "proofs": n, "variables_per_proof": prog.n_vars,
-                   "levels": int(len(prog.level_offsets) - 1), "poseidon_invocations": s["flow_count"] * args.copies,
+                   "levels": int(len(prog.level_offsets) - 1), "poseidon_invocations": s["flow_count"] * args.copies, "layout": args.layout,
                    "output_bytes_per_proof": 16 * prog.n_vars, "scratch_bytes": wp.scratch_bytes(n), "program_build_s": round(build_s, 2)},
         "split_ms": {"verifying_pass_with_hints": hints_ms, "levels_and_transpose": eval_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,

@@ -11,6 +11,7 @@ timeout -k 10 300 python bench.py --workload copies --proofs 65536 --emit-paths 
 timeout -k 10 300 python bench.py --proofs 131072 --steps 3 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_131072_config3_shard.json 2> $OUT/shard.err; echo shard done
 timeout -k 10 500 python bench.py --total-proofs 1048576 --steps 1 --warmup 1 --cpu-sample 0 --perm-log2 0 > $OUT/bench_total_1048576_1gpu.json 2> $OUT/total.err; echo total done
 for N in 1 256 1024 4096 16384; do timeout -k 10 250 python tools/bench_witness.py --fixture level10-1.bin --proofs $N > $OUT/witness_level10_$N.json 2> $OUT/witness.err || tail -3 $OUT/witness.err; done
+timeout -k 10 250 python tools/bench_witness.py --fixture level10-1.bin --proofs 16384 --layout by_variable > $OUT/witness_level10_16384_by_variable.json 2> $OUT/witness.err || tail -3 $OUT/witness.err
 timeout -k 10 250 python tools/bench_witness.py --fixture level1-5.bin --proofs 1024 > $OUT/witness_level1_1024.json 2> $OUT/witness.err || tail -3 $OUT/witness.err
 timeout -k 10 250 python tools/bench_witness.py --fixture recursive_proof_16_15.bin --copies 5 --proofs 1024 > $OUT/witness_rec16_x5_1024.json 2> $OUT/witness.err || tail -3 $OUT/witness.err
 (cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/witness_kt -o kt -- python3 $OLDPWD/tools/bench_witness.py --fixture level10-1.bin --proofs 4096 --steps 2 > $OLDPWD/$OUT/witness_under_rocprof.json 2> $OLDPWD/$OUT/witness_kt.err); find $OUT/witness_kt -name "*kernel_trace.csv" -size +8M -delete; echo witness done
@@ -19,7 +20,7 @@ timeout -k 10 300 python tests/soak.py 1500 31 - single 300 > $OUT/soak.txt 2>&1
 timeout -k 10 300 python tests/soak.py 1500 32 pow0 >> $OUT/soak.txt 2>&1; tail -1 $OUT/soak.txt
 python3 - <<'PY'
 import json
-for f in ("bench_flow_65536","bench_all_hints_65536","bench_131072_config3_shard","bench_total_1048576_1gpu","witness_level10_1","witness_level10_256","witness_level10_1024","witness_level10_4096","witness_level10_16384","witness_level1_1024","witness_rec16_x5_1024"):
+for f in ("bench_flow_65536","bench_all_hints_65536","bench_131072_config3_shard","bench_total_1048576_1gpu","witness_level10_1","witness_level10_256","witness_level10_1024","witness_level10_4096","witness_level10_16384","witness_level10_16384_by_variable","witness_level1_1024","witness_rec16_x5_1024"):
     try:
         d=json.load(open("gpurun_out/r3_art/%s.json"%f)); print(f, round(d["value"]), round(d["ms_per_step"],2))
     except Exception as e: print(f,"FAILED",e)
