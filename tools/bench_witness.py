@@ -104,7 +104,7 @@ def main():
                    "output_bytes_per_proof": 16 * prog.n_vars, "scratch_bytes": wp.scratch_bytes(n), "program_build_s": round(build_s, 2)},
         "split_ms": {"verifying_pass_with_hints": hints_ms, "levels_and_transpose": eval_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "note": f"k_witness_level x {len(prog.level_offsets) - 1} launches + k_witness_transpose; algorithmic bytes/proof "
+                     "note": f"k_witness_level per level ({len(prog.level_offsets) - 1} levels, the narrow tail in one k_witness_strip launch) + k_witness_transpose; algorithmic bytes/proof "
                              f"{bytes_per_proof} = 16 B written per variable, 16 B per variable operand ({2 * n_two + n_one}), hint sources, "
                              "32 B per variable for the transpose"},
         "kernel_sources_sha": bench.kernel_sources_sha()}))
