@@ -472,7 +472,7 @@ void rsv_witness_program_destroy(rsv_witness_program* prog);
  * reference's gadgets (csrc/circuit_{cs,gadgets,verifier}.hpp: ConstraintSystemRef, M31Var .. QM31Var, BitsVar,
  * Poseidon2HalfVar, ChannelVar, the Merkle hasher, circle points, LinePolyVar, query positions; PlonkWithPoseidonProofVar,
  * FiatShamirResults, CompositionCheck, AnswerResults, FoldingResults) once over the template on the host, fed with the
- * hints of the GPU's verifying pass over it.  ~0.1 s per 50 000 variables. */
+ * hints of the GPU's verifying pass over it.  A few milliseconds per 50 000 variables, plus that one verifying pass. */
 int rsv_witness_program_build(const uint8_t* proof, size_t len, const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
                               uint32_t copies, int device, rsv_witness_program** out);
 /* Sizes, then the arrays (any pointer may be NULL): instr [n_vars][8], level_offsets [n_levels + 1], flow_wires
@@ -485,8 +485,8 @@ int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t*
 /* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and
  * writes d_variables [n][n_vars][4]: row i = the `variables` vector of the circuit that verifies proof i
  * ([n_vars][n][4] under RSV_OPT_WITNESS_LAYOUT = 2).
- * d_accept[i] = 1 iff proof i verified AND is of the program's shape; only those rows are defined (the others hold the
- * constants and zeros).  d_variables 16-byte aligned.
+ * d_accept[i] = 1 iff proof i verified AND is of the program's shape; only those rows are defined (the others are
+ * unspecified).  d_variables 16-byte aligned.
  * d_flow [n][flow_count][32] + d_flow_swap [n][flow_count] (optional, both or neither; as rsv_hints_out::d_flow with
  * flow_stride = the shape's flow_count): the PoseidonFlow of ONE copy of the verifier — the other thing the next prover
  * needs; every copy invokes the same permutations, the wire indices of invocation k of copy c are the host's
