@@ -118,6 +118,38 @@ def test_witness_of_five_copies_in_one_circuit(rsv):
     wp.close()
 
 
+@pytest.mark.parametrize("src", ["level6-1.bin", "level12-1.bin"])
+def test_gpu_witness_is_what_the_next_fixture_proves(rsv, src):
+    """The GPU's vector against the REFERENCE directly: fixture K+1 is the proof of the circuit that verifies fixture K, so
+    the 12 trace columns a_val / b_val / c_val of that circuit — the GPU's `variables` of K read through the wires —
+    interpolated and evaluated at K+1's OODS point, are the sampled values K+1 carries (tests/test_recursion_circuit.py does
+    this with the oracle's values on the CPU).  For the two pairs whose recorded HashSet walk is the library's fixed one."""
+    import json
+    import os
+    from oracle import recursion_circuit as rc
+    from oracle.recursion_circuit import trace as T
+    from tests.conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "recursion_circuit_pins.json")) as f:
+        pin = next(p for p in json.load(f)["pairs"] if p["src"] == src)
+    assert pin["shift_orders"] == [[[0, -1], [0, -1]]] and pin["multiplier"] == 1
+    wp = rsv.WitnessProgram.build(read_proof(src), fixture_cfg(src), _inputs(src))
+    variables, accept, _ = rsv.witness([read_proof(src)], wp, _inputs(src))
+    assert accept[0] == 1
+    c, _, _ = rc.build_circuit(read_proof(src), ob, _inputs(src))  # for the gate list only: the values come from the GPU
+    c.variables = [tuple(int(x) for x in v) for v in variables[0]]
+    nxt = read_proof(pin["dst"])
+    tr = ob.transcript_raw(nxt)
+    oods = (tuple(int(x) for x in tr[20:24]), tuple(int(x) for x in tr[24:28]))
+    want = rc.parse_proof(nxt).sampled_values
+    lp = int(np.frombuffer(nxt[:4], np.uint32)[0])
+    assert T.pad(c) == 1 << lp
+    _, trace = T.plonk_columns(c)
+    pe = T.PointEvaluator(lp, oods)
+    for k in range(12):
+        assert pe.eval(trace[k]) == want[1][k][0], k
+    wp.close()
+
+
 def test_build_refuses_what_is_not_a_template(rsv):
     """A template has to verify under the given configuration and inputs; anything else is an error code, not a program."""
     name = "level12-1.bin"
