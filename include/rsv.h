@@ -472,9 +472,14 @@ void rsv_witness_program_destroy(rsv_witness_program* prog);
  * reference's gadgets (csrc/circuit_{cs,gadgets,verifier}.hpp: ConstraintSystemRef, M31Var .. QM31Var, BitsVar,
  * Poseidon2HalfVar, ChannelVar, the Merkle hasher, circle points, LinePolyVar, query positions; PlonkWithPoseidonProofVar,
  * FiatShamirResults, CompositionCheck, AnswerResults, FoldingResults) once over the template on the host, fed with the
- * hints of the GPU's verifying pass over it.  A few milliseconds per 50 000 variables, plus that one verifying pass. */
+ * hints of the GPU's verifying pass over it.  A few milliseconds per 50 000 variables, plus that one verifying pass.
+ * set_walks (NULL = all zero): one byte per copy.  AnswerResults::compute walks two std HashSet<isize> = {0, -1} whose
+ * order Rust seeds per process (components/recursive/answer/src/lib.rs:44-71), so the reference's own circuit comes in
+ * four variants per copy that differ in the ORDER of two pairs of blocks of variables (the values are the same); bit 0 =
+ * the Plonk set is walked -1 first, bit 1 = the Poseidon set.  A prover that already fixed its gate list (preprocessed
+ * columns) passes the walks that list was made with. */
 int rsv_witness_program_build(const uint8_t* proof, size_t len, const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
-                              uint32_t copies, int device, rsv_witness_program** out);
+                              uint32_t copies, const uint8_t* set_walks, int device, rsv_witness_program** out);
 /* Sizes, then the arrays (any pointer may be NULL): instr [n_vars][8], level_offsets [n_levels + 1], flow_wires
  * [copies * flow_count][5] = PoseidonEntry::wire of r1..r4 and SwapOption::addr of every invocation (constants of the
  * shape; known to built programs only, RSV_E_SIZE otherwise) — what rsv_witness_program_create takes back. */

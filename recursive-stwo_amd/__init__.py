@@ -194,7 +194,7 @@ def _load() -> ctypes.CDLL:
                                                       ctypes.POINTER(ctypes.c_void_p)]),
         "rsv_witness_program_destroy": (None, [vp]),
         "rsv_witness_program_build": (ctypes.c_int, [_u8p, sz, ctypes.POINTER(PcsConfig), ctypes.POINTER(PublicInput), sz, ctypes.c_uint32,
-                                                     ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+                                                     _u8p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
         "rsv_witness_program_info": (ctypes.c_int, [vp, _u32p, _u32p, ctypes.POINTER(WitnessShape)]),
         "rsv_witness_program_export": (ctypes.c_int, [vp, _u32p, _u32p, _u32p]),
         "rsv_witness_scratch_bytes": (ctypes.c_int, [vp, sz, ctypes.POINTER(sz)]),
@@ -550,13 +550,18 @@ class WitnessProgram:
         self.n_vars, self.n_levels = int(n_vars.value), int(n_levels.value)
 
     @classmethod
-    def build(cls, proof: bytes, cfg, inputs=STANDARD_INPUTS, copies: int = 1, device: int = 0) -> "WitnessProgram":
+    def build(cls, proof: bytes, cfg, inputs=STANDARD_INPUTS, copies: int = 1, device: int = 0, set_walks=None) -> "WitnessProgram":
+        """set_walks: per copy, which of the four orders the reference's two HashSet walks took (rsv.h); default 0 for all."""
         b = np.frombuffer(proof, dtype=np.uint8)
+        walks = None if set_walks is None else np.ascontiguousarray(set_walks, dtype=np.uint8)
+        if walks is not None and len(walks) != copies:
+            raise ValueError("set_walks: one entry per copy")
         c = PcsConfig(cfg.pow_bits, cfg.log_blowup_factor, cfg.log_last_layer_degree_bound, cfg.n_queries)
         pi = make_inputs(inputs)
         h = ctypes.c_void_p()
-        _check(lib.rsv_witness_program_build(b.ctypes.data_as(_u8p), len(proof), ctypes.byref(c), pi, len(list(inputs)), copies, device,
-                                             ctypes.byref(h)), "rsv_witness_program_build")
+        _check(lib.rsv_witness_program_build(b.ctypes.data_as(_u8p), len(proof), ctypes.byref(c), pi, len(list(inputs)), copies,
+                                             walks.ctypes.data_as(_u8p) if walks is not None else None, device, ctypes.byref(h)),
+               "rsv_witness_program_build")
         return cls(_handle=h)
 
     def export(self):

@@ -6,7 +6,8 @@
 //
 // AnswerResults::compute walks two std HashSet<isize> = {0, -1} to build the shifted OODS points (answer/src/lib.rs:44-71):
 // Rust seeds them per process, so the reference's own circuit differs from run to run in the order of two pairs of blocks.
-// This builder takes 0 before -1 for both (any order is one the reference produces).
+// The builder takes 0 before -1 for both unless told otherwise per copy (`walk`: bit 0 = the Plonk set is walked -1 first,
+// bit 1 = the Poseidon set) — any order is one the reference produces; a given run of the reference used one of the four.
 #pragma once
 #include <algorithm>
 #include <map>
@@ -586,7 +587,7 @@ inline std::vector<Var> fri_answers_for_log_size(ConstraintSystem* cs, const std
     return evals;
 }
 
-inline Answer answer(Gadgets& g, const ProofVar& pv, const Template& d, const FiatShamir& fs) {
+inline Answer answer(Gadgets& g, const ProofVar& pv, const Template& d, const FiatShamir& fs, uint32_t walk) {
     ConstraintSystem* cs = g.cs;
     Answer ans;
     // CirclePointQM31Var::new_witness(&cs, &fiat_shamir_hints.oods_point) (examples/multi-proofs/src/main.rs:108)
@@ -595,10 +596,14 @@ inline Answer answer(Gadgets& g, const ProofVar& pv, const Template& d, const Fi
     oods_point.y = qm31_witness(cs, fs.oods_point.y.value, mk_instr(W_COPY, fs.oods_point.y.variable));
     const Pt step_plonk = canonic_coset(d.lp).step, step_poseidon = canonic_coset(d.lq).step;
     PointQM31 shifted_plonk[2], shifted_poseidon[2];  // [0] = shift 0, [1] = shift -1
-    shifted_plonk[0] = pq_add_const(oods_point, cp_mul(step_plonk, 0));
-    shifted_plonk[1] = pq_add_const(oods_point, cp_mul(step_plonk, 0x7fffffffu));
-    shifted_poseidon[0] = pq_add_const(oods_point, cp_mul(step_poseidon, 0));
-    shifted_poseidon[1] = pq_add_const(oods_point, cp_mul(step_poseidon, 0x7fffffffu));
+    for (int k = 0; k < 2; k++) {
+        const int which = (walk & 1u) ? 1 - k : k;
+        shifted_plonk[which] = pq_add_const(oods_point, cp_mul(step_plonk, which ? 0x7fffffffu : 0u));
+    }
+    for (int k = 0; k < 2; k++) {
+        const int which = (walk & 2u) ? 1 - k : k;
+        shifted_poseidon[which] = pq_add_const(oods_point, cp_mul(step_poseidon, which ? 0x7fffffffu : 0u));
+    }
 
     // samples[tree][column] = [(shift key, point, value)]
     std::vector<std::vector<std::vector<Sample>>> samples(4);
@@ -720,14 +725,14 @@ inline void folding(Gadgets& g, const ProofVar& pv, const Template& d, const Fia
 }
 
 // One copy of the verifier: the body of the `multipliers` loop (examples/multi-proofs/src/main.rs:66-139)
-inline void verify_in_circuit(Gadgets& g, const Template& d, const std::vector<std::pair<uint32_t, Q4>>& public_inputs) {
+inline void verify_in_circuit(Gadgets& g, const Template& d, const std::vector<std::pair<uint32_t, Q4>>& public_inputs, uint32_t walk) {
     ConstraintSystem* cs = g.cs;
     std::vector<std::pair<uint32_t, Var>> inputs;
     for (const auto& [idx, val] : public_inputs) inputs.push_back({idx, qm31_constant(cs, val)});
     ProofVar pv = allocate_proof(cs, d);
     const FiatShamir fs = fiat_shamir(g, pv, d, inputs);
     composition_check(pv, d, fs);
-    Answer ans = answer(g, pv, d, fs);
+    Answer ans = answer(g, pv, d, fs, walk);
     folding(g, pv, d, fs, ans);
 }
 

@@ -430,12 +430,14 @@ struct WitnessProgram {
     std::vector<std::array<uint32_t, 5>> flow_wires;
 
     // `multipliers` copies of the verifier of proofs shaped like `template_proof` (which must verify under config / inputs)
-    static WitnessProgram build(const std::vector<uint8_t>& template_proof, const PcsConfig& config, const Inputs& inputs, uint32_t multipliers = 1) {
+    static WitnessProgram build(const std::vector<uint8_t>& template_proof, const PcsConfig& config, const Inputs& inputs, uint32_t multipliers = 1,
+                                const std::vector<uint8_t>& set_walks = {}) {
         WitnessProgram p;
         const rsv_pcs_config abi_cfg = config.abi();
         auto pi = abi_inputs(inputs);
-        check(rsv_witness_program_build(template_proof.data(), template_proof.size(), &abi_cfg, pi.data(), pi.size(), multipliers, default_device(),
-                                        &p.handle), "rsv_witness_program_build");
+        if (!set_walks.empty() && set_walks.size() != multipliers) throw std::runtime_error("set_walks: one entry per copy");
+        check(rsv_witness_program_build(template_proof.data(), template_proof.size(), &abi_cfg, pi.data(), pi.size(), multipliers,
+                                        set_walks.empty() ? nullptr : set_walks.data(), default_device(), &p.handle), "rsv_witness_program_build");
         check(rsv_witness_program_info(p.handle, &p.n_vars, nullptr, &p.shape), "rsv_witness_program_info");
         p.flow_wires.resize((size_t)p.shape.copies * p.shape.flow_count);
         check(rsv_witness_program_export(p.handle, nullptr, nullptr, &p.flow_wires[0][0]), "rsv_witness_program_export");

@@ -118,24 +118,31 @@ def test_witness_of_five_copies_in_one_circuit(rsv):
     wp.close()
 
 
-@pytest.mark.parametrize("src", ["level6-1.bin", "level12-1.bin"])
-def test_gpu_witness_is_what_the_next_fixture_proves(rsv, src):
-    """The GPU's vector against the REFERENCE directly: fixture K+1 is the proof of the circuit that verifies fixture K, so
-    the 12 trace columns a_val / b_val / c_val of that circuit — the GPU's `variables` of K read through the wires —
-    interpolated and evaluated at K+1's OODS point, are the sampled values K+1 carries (tests/test_recursion_circuit.py does
-    this with the oracle's values on the CPU).  For the two pairs whose recorded HashSet walk is the library's fixed one."""
+def _pins():
     import json
     import os
-    from oracle import recursion_circuit as rc
-    from oracle.recursion_circuit import trace as T
     from tests.conftest import GOLDEN
     with open(os.path.join(GOLDEN, "recursion_circuit_pins.json")) as f:
-        pin = next(p for p in json.load(f)["pairs"] if p["src"] == src)
-    assert pin["shift_orders"] == [[[0, -1], [0, -1]]] and pin["multiplier"] == 1
-    wp = rsv.WitnessProgram.build(read_proof(src), fixture_cfg(src), _inputs(src))
+        return json.load(f)["pairs"]
+
+
+@pytest.mark.parametrize("pin", _pins(), ids=lambda p: f"{p['src']}x{p['multiplier']}")
+def test_gpu_witness_is_what_the_next_fixture_proves(rsv, pin):
+    """The GPU's vector against the REFERENCE directly, for all 14 consecutive fixture pairs: fixture K+1 is the proof of the
+    circuit that verifies fixture K (`multiplier` times), so the 12 trace columns a_val / b_val / c_val of that circuit —
+    the GPU's `variables` of K read through the wires — interpolated and evaluated at K+1's OODS point, are the sampled
+    values K+1 carries.  The library's builder is told which way the reference's run walked its two HashSets for that
+    fixture (set_walks, from the recorded pins); the gate list comes from the oracle's run with the same walks."""
+    from oracle import recursion_circuit as rc
+    from oracle.recursion_circuit import trace as T
+    src, mult = pin["src"], pin["multiplier"]
+    orders = [tuple(tuple(x) for x in o) for o in pin["shift_orders"]]
+    walks = [(1 if o[0] == (-1, 0) else 0) | (2 if o[1] == (-1, 0) else 0) for o in orders]
+    wp = rsv.WitnessProgram.build(read_proof(src), fixture_cfg(src), _inputs(src), copies=mult, set_walks=walks)
     variables, accept, _ = rsv.witness([read_proof(src)], wp, _inputs(src))
     assert accept[0] == 1
-    c, _, _ = rc.build_circuit(read_proof(src), ob, _inputs(src))  # for the gate list only: the values come from the GPU
+    c, _, _ = rc.build_circuit(read_proof(src), ob, _inputs(src), mult, orders)  # for the gate list: the values come from the GPU
+    assert len(c.variables) == wp.n_vars
     c.variables = [tuple(int(x) for x in v) for v in variables[0]]
     nxt = read_proof(pin["dst"])
     tr = ob.transcript_raw(nxt)
