@@ -102,6 +102,34 @@ def test_builder_writes_the_oracles_program_for_every_fixture_shape(rsv, manifes
     assert len(seen) >= 10
 
 
+def test_builder_follows_the_four_hashset_walks(rsv):
+    """set_walks: for each of the four orders in which a run of the reference can walk its two HashSets (and a mix of
+    them over three copies) the builder writes the program of the oracle's circuit under the same orders; the four programs
+    differ from each other, their value multisets do not."""
+    from oracle import recursion_circuit as rc
+    name = "level12-1.bin"
+    proof, inputs, cfg = read_proof(name), _inputs(name), fixture_cfg(name)
+    order_of = {0: ((0, -1), (0, -1)), 1: ((-1, 0), (0, -1)), 2: ((0, -1), (-1, 0)), 3: ((-1, 0), (-1, 0))}
+    progs = []
+    for walks in ([0], [1], [2], [3], [2, 0, 3]):
+        wp = rsv.WitnessProgram.build(proof, cfg, inputs, copies=len(walks), set_walks=walks)
+        prog = wp.export()
+        c, d, _ = rc.build_circuit(proof, ob, inputs, len(walks), [order_of[w] for w in walks])
+        ref = rc.program.extract(c, d, len(walks))
+        assert np.array_equal(prog.instr, ref.instr) and np.array_equal(prog.level_offsets, ref.level_offsets), walks
+        assert np.array_equal(prog.flow_wires, ref.flow_wires), walks
+        if len(walks) == 1:
+            variables, accept, _ = rsv.witness([proof], wp, inputs)
+            assert accept[0] == 1 and np.array_equal(variables[0], np.array(c.variables, dtype=np.uint32))
+            progs.append((prog, variables[0]))
+        wp.close()
+    for k in range(1, 4):
+        assert not np.array_equal(progs[0][0].instr, progs[k][0].instr)
+        assert np.array_equal(np.sort(progs[0][1].view("u4,u4,u4,u4").ravel()), np.sort(progs[k][1].view("u4,u4,u4,u4").ravel()))
+    with pytest.raises(ValueError):
+        rsv.WitnessProgram.build(proof, cfg, inputs, copies=2, set_walks=[0])
+
+
 def test_witness_of_five_copies_in_one_circuit(rsv):
     """examples/multi-proofs verifies recursive_proof_16_15.bin five times in one circuit (main.rs:64, 173-196):
     the program of that circuit (about 330 000 variables; its 291 870 Plonk rows are the level1 fixture's 2^19)."""
