@@ -185,6 +185,43 @@ def test_gpu_witness_is_what_the_next_fixture_proves(rsv, pin):
     wp.close()
 
 
+@pytest.mark.parametrize("pin", _pins(), ids=lambda p: f"{p['src']}x{p['multiplier']}")
+def test_gpu_flow_is_the_next_fixtures_poseidon_component(rsv, pin):
+    """The same for the PoseidonFlow the call returns, all 14 pairs: the GPU's records (hashes + swap bits; one copy's,
+    repeated per copy) with the program's wire indices, padded and laid out six rows per invocation, ARE the Poseidon
+    component of the next fixture — all 40 preprocessed and 48 trace columns evaluate to its sampled values at its OODS point."""
+    import ctypes
+    from oracle import recursion_circuit as rc
+    from oracle.recursion_circuit import trace as T
+    src, mult = pin["src"], pin["multiplier"]
+    orders = [tuple(tuple(x) for x in o) for o in pin["shift_orders"]]
+    walks = [(1 if o[0] == (-1, 0) else 0) | (2 if o[1] == (-1, 0) else 0) for o in orders]
+    wp = rsv.WitnessProgram.build(read_proof(src), fixture_cfg(src), _inputs(src), copies=mult, set_walks=walks)
+    _, accept, _, flow, swap = rsv.witness([read_proof(src)], wp, _inputs(src), with_flow=True)
+    wires = wp.export().flow_wires
+    count = flow.shape[1]
+    assert accept[0] == 1 and len(wires) == mult * count
+    recs = [((int(w[0]), tuple(int(x) for x in f[0:8])), (int(w[1]), tuple(int(x) for x in f[8:16])), (int(w[2]), tuple(int(x) for x in f[16:24])),
+             (int(w[3]), tuple(int(x) for x in f[24:32])), int(w[4]), bool(sw))
+            for w, f, sw in zip(wires, np.tile(flow[0], (mult, 1)), np.tile(swap[0], mult))]
+    for _ in range(len(recs), max(32, -(-len(recs) // 16) * 16)):  # PlonkWithPoseidonConstraintSystem::pad
+        recs.append(((0, None), (0, None), (0, None), (0, None), 0, False))
+    ob.lib.rsvo_round_constants.restype = ctypes.POINTER(ctypes.c_uint32)
+    r = [ob.lib.rsvo_round_constants(k) for k in range(3)]
+    rcs = ([[int(r[0][16 * a + i]) for i in range(16)] for a in range(4)], [int(r[1][i]) for i in range(14)],
+           [[int(r[2][16 * a + i]) for i in range(16)] for a in range(4)])
+    nxt = read_proof(pin["dst"])
+    tr = ob.transcript_raw(nxt)
+    oods = (tuple(int(x) for x in tr[20:24]), tuple(int(x) for x in tr[24:28]))
+    want = rc.parse_proof(nxt).sampled_values
+    lq = int(np.frombuffer(nxt[:8], np.uint32)[1])
+    qpre, qtr = T.poseidon_columns(recs, rcs, lq, padding_hash=([0] * 8,))
+    pe = T.PointEvaluator(lq, oods)
+    assert all(pe.eval(qpre[k]) == want[0][10 + k][0] for k in range(40))
+    assert all(pe.eval(qtr[k]) == want[1][12 + k][0] for k in range(48))
+    wp.close()
+
+
 def test_build_refuses_what_is_not_a_template(rsv):
     """A template has to verify under the given configuration and inputs; anything else is an error code, not a program."""
     name = "level12-1.bin"
