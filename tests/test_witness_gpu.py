@@ -222,6 +222,49 @@ def test_gpu_flow_is_the_next_fixtures_poseidon_component(rsv, pin):
     wp.close()
 
 
+def test_one_context_many_shapes_and_batch_sizes(rsv):
+    """Soak of the scratch handling: ONE context, programs of five shapes used in turn, batch sizes 1 … 150 in random order,
+    a random subset of every batch tampered (and one proof of a foreign shape): accept flags as rsv_verify_batch's, every
+    accepted row equal to the oracle's vector for that proof — nothing of an earlier batch or shape leaks into a later one."""
+    import torch
+    rng = np.random.default_rng(7)
+    dev = torch.device("cuda:0")
+    ctx = rsv.Context(0)
+    pairs = [("level10-1.bin", "level11-1.bin"), ("level12-1.bin", "level12-1.bin"), ("level2-1.bin", "level5-1.bin"), ("small_proof.bin", "small_proof.bin"),
+             ("level7-1.bin", "level7-1.bin")]
+    progs, wants = {}, {}
+    for a, b in pairs:
+        progs[a] = rsv.WitnessProgram.build(read_proof(a), fixture_cfg(a), _inputs(a))
+        for x in (a, b):
+            wants[x] = _oracle_variables(x)[0]
+    for it in range(12):
+        a, b = pairs[int(rng.integers(len(pairs)))]
+        wp, n = progs[a], int(rng.choice([1, 2, 3, 17, 64, 65, 150]))
+        names = [a if rng.random() < 0.5 else b for _ in range(n)]
+        batch = [read_proof(x) for x in names]
+        bad = set(int(i) for i in np.nonzero(rng.random(n) < 0.3)[0])
+        for i in bad:
+            batch[i] = ob.tamper(batch[i], 1000 * it + i)
+        foreign = int(rng.integers(n)) if n > 2 else None
+        if foreign is not None:
+            batch[foreign] = read_proof("level9-1.bin" if a != "level9-1.bin" else "level8-1.bin")
+        blob, offsets = rsv.pack(batch)
+        d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        d_vars = torch.full((n, wp.n_vars, 4), -1, dtype=torch.int32, device=dev)
+        d_acc = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(a))
+        ctx.synchronize()
+        acc, got = d_acc.cpu().numpy(), d_vars.cpu().numpy().view(np.uint32)
+        for i in range(n):
+            good = i not in bad and i != foreign
+            assert acc[i] == (1 if good else 0), (it, a, n, i)
+            if good:
+                assert np.array_equal(got[i], wants[names[i]]), (it, a, n, i)
+    ctx.close()
+    for wp in progs.values():
+        wp.close()
+
+
 def test_build_refuses_what_is_not_a_template(rsv):
     """A template has to verify under the given configuration and inputs; anything else is an error code, not a program."""
     name = "level12-1.bin"
