@@ -485,6 +485,15 @@ int rsv_witness_program_build(const uint8_t* proof, size_t len, const rsv_pcs_co
  * shape; known to built programs only, RSV_E_SIZE otherwise) — what rsv_witness_program_create takes back. */
 int rsv_witness_program_info(const rsv_witness_program* prog, uint32_t* n_vars, uint32_t* n_levels, rsv_witness_shape* shape);
 int rsv_witness_program_export(const rsv_witness_program* prog, uint32_t* instr, uint32_t* level_offsets, uint32_t* flow_wires);
+/* The circuit's gate list as the gadgets left it (built programs only, RSV_E_SIZE otherwise): gates [n_rows][6] =
+ * a_wire, b_wire, c_wire, op, poseidon_wire, enforce_c_m31 per Plonk row (plonk_with_poseidon.rs:23-36, before pad()) —
+ * with `variables` and the flow everything generate_plonk_with_poseidon_circuit (:522-629) and populate_logup_arguments
+ * (:345-466) read.  The rows are constants of the shape EXCEPT `op` at the rows listed in witness_ops [n][3] = (row, bit
+ * variable, constant): CirclePointM31Var::select takes its gate constant from the selected value
+ * (primitives/circle/src/lib.rs:83-98), so there op = constant where the proof's variables[bit] is 1 and 0 where it is 0;
+ * `gates` holds the template's.  Call with NULL arrays for the two counts first. */
+int rsv_witness_program_gates(const rsv_witness_program* prog, uint32_t* n_rows, uint32_t* n_witness_ops, uint32_t* gates,
+                              uint32_t* witness_ops);
 /* HBM the context will hold for a batch of n proofs (hints of the verifying pass + variables[var][proof]). */
 int rsv_witness_scratch_bytes(const rsv_witness_program* prog, size_t n, size_t* bytes);
 /* Verifies the batch (as rsv_verify_hints_dev, under cfg = the program's single configuration, else RSV_E_SIZE) and

@@ -197,6 +197,7 @@ def _load() -> ctypes.CDLL:
                                                      _u8p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
         "rsv_witness_program_info": (ctypes.c_int, [vp, _u32p, _u32p, ctypes.POINTER(WitnessShape)]),
         "rsv_witness_program_export": (ctypes.c_int, [vp, _u32p, _u32p, _u32p]),
+        "rsv_witness_program_gates": (ctypes.c_int, [vp, _u32p, _u32p, _u32p, _u32p]),
         "rsv_witness_scratch_bytes": (ctypes.c_int, [vp, sz, ctypes.POINTER(sz)]),
         "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp, vp, vp]),
         "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u32p, _u8p,
@@ -218,7 +219,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_trace_paths", "rsv_fri_paths_dev", "rsv_fri_paths", "rsv_verify_hints_dev", "rsv_verify_hints", "rsv_verify_batch_host", "rsv_field_op", "rsv_domain_points",
            "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
            "rsv_transcript_batch", "rsv_poseidon_flow_count", "rsv_witness_program_create", "rsv_witness_program_destroy",
-           "rsv_witness_program_build", "rsv_witness_program_info", "rsv_witness_program_export",
+           "rsv_witness_program_build", "rsv_witness_program_info", "rsv_witness_program_export", "rsv_witness_program_gates",
            "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval"]
 
 
@@ -580,6 +581,19 @@ class WitnessProgram:
         shape = dict(zip(witness_program.SHAPE_KEYS, (s.log_size_plonk, s.log_size_poseidon, s.pow_bits, s.log_blowup, s.log_last, s.n_queries,
                                               s.n_inner, s.flow_count, s.copies)))
         return witness_program.Program(instr, levels, self.n_vars, shape, wires)
+
+    def gates(self, variables=None):
+        """The circuit's Plonk rows (rsv_witness_program_gates): uint32[n_rows, 6] = a_wire, b_wire, c_wire, op,
+        poseidon_wire, enforce_c_m31 — the template's; with `variables` (uint32[n_vars, 4] of another proof of the shape) the
+        rows whose op follows the witness are set for that proof.  Also returns witness_ops uint32[n, 3]."""
+        n_rows, n_ops = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _check(lib.rsv_witness_program_gates(self._h, ctypes.byref(n_rows), ctypes.byref(n_ops), None, None), "rsv_witness_program_gates")
+        rows = np.zeros((n_rows.value, 6), np.uint32)
+        ops = np.zeros((n_ops.value, 3), np.uint32)
+        _check(lib.rsv_witness_program_gates(self._h, None, None, rows.ctypes.data_as(_u32p), ops.ctypes.data_as(_u32p)), "rsv_witness_program_gates")
+        if variables is not None:
+            rows[ops[:, 0], 3] = np.where(variables[ops[:, 1], 0] != 0, ops[:, 2], 0)
+        return rows, ops
 
     def close(self):
         if getattr(self, "_h", None):

@@ -66,15 +66,18 @@ struct FlowRecord {           // one Poseidon2HalfVar::permute invocation (plonk
 
 enum Mode { WITNESS, CONSTANT };
 
-// PlonkWithPoseidonConstraintSystem (plonk_with_poseidon.rs:17-283), the parts a witness program needs: the values, how
-// each came to be, the flow's wires.  (The gate rows themselves — wires, op — are not kept: they are the reference's
-// business; tests compare this builder's programs with the CPU checker's, which does keep them.)
+struct GateRow { uint32_t a, b, c, op, poseidon_wire, enforce_c_m31; };  // one Plonk row (plonk_with_poseidon.rs:23-36)
+struct WitnessOp3 { uint32_t row, bit, constant; };  // a row whose `op` follows the witness: op = variables[bit] ? constant : 0
+
+// PlonkWithPoseidonConstraintSystem (plonk_with_poseidon.rs:17-283): the values, how each came to be, the gate rows, the
+// flow's wires.
 struct ConstraintSystem {
     std::vector<Q4> variables;
     std::vector<Instr> origin;
     std::vector<FlowRecord> flow;
+    std::vector<GateRow> rows;
+    std::vector<WitnessOp3> witness_ops;
     std::unordered_map<std::string, uint32_t> cache;
-    size_t n_rows = 4;
     bool have_hint = false;
     Instr hint{};
 
@@ -84,25 +87,47 @@ struct ConstraintSystem {
             Instr in = mk_instr(W_CONST, 0, 0, variables[k][0], variables[k][1], variables[k][2], variables[k][3]);
             in.dst = k;
             origin.push_back(in);
+            rows.push_back(GateRow{k, 0, k, 1, 0, 0});
         }
     }
+    void row(uint32_t a, uint32_t b, uint32_t c, uint32_t op, uint32_t pw = 0, uint32_t m31 = 0) { rows.push_back(GateRow{a, b, c, op, pw, m31}); }
     uint32_t push(const Q4& v, Instr in) {
         in.dst = (uint32_t)variables.size();
         variables.push_back(v);
         origin.push_back(in);
         return in.dst;
     }
-    void insert_gate() { n_rows++; }
-    void enforce_zero() { n_rows++; }
-    uint32_t add(uint32_t a, uint32_t b) { n_rows++; return push(hq_add(variables[a], variables[b]), mk_instr(W_ADD, a, b)); }
-    uint32_t mul(uint32_t a, uint32_t b) { n_rows++; return push(hq_mul(variables[a], variables[b]), mk_instr(W_MUL, a, b)); }
-    uint32_t assemble_poseidon_gate(uint32_t a, uint32_t b) { return mul(a, b); }
-    // program_k: the constant the program uses where the reference's gate constant follows the witness (pm_select)
-    uint32_t mul_constant(uint32_t a, uint32_t k, uint32_t program_k) {
-        n_rows++;
-        return push(hq_scale(variables[a], k), mk_instr(W_MULC, a, 0, program_k));
+    void insert_gate(uint32_t a, uint32_t b, uint32_t c, uint32_t op) { row(a, b, c, op); }
+    void enforce_zero(uint32_t var) { row(var, 0, 0, 1); }
+    uint32_t add(uint32_t a, uint32_t b) {
+        const uint32_t c = push(hq_add(variables[a], variables[b]), mk_instr(W_ADD, a, b));
+        row(a, b, c, 1);
+        return c;
     }
-    uint32_t mul_constant(uint32_t a, uint32_t k) { return mul_constant(a, k, k); }
+    uint32_t mul(uint32_t a, uint32_t b) {
+        const uint32_t c = push(hq_mul(variables[a], variables[b]), mk_instr(W_MUL, a, b));
+        row(a, b, c, 0);
+        return c;
+    }
+    uint32_t assemble_poseidon_gate(uint32_t a, uint32_t b) {
+        const uint32_t c = push(hq_mul(variables[a], variables[b]), mk_instr(W_MUL, a, b));
+        row(a, b, c, 0, c);
+        return c;
+    }
+    // program_k: the constant the program uses where the reference's gate constant follows the witness (pm_select): the
+    // gate row keeps the reference's constant for the template and is listed in witness_ops for every other proof
+    uint32_t mul_constant(uint32_t a, uint32_t k, uint32_t program_k) {
+        const uint32_t c = push(hq_scale(variables[a], k), mk_instr(W_MULC, a, 0, program_k));
+        witness_ops.push_back(WitnessOp3{(uint32_t)rows.size(), a, program_k});
+        row(a, 0, c, k);
+        return c;
+    }
+    uint32_t mul_constant_plain(uint32_t a, uint32_t k) {
+        const uint32_t c = push(hq_scale(variables[a], k), mk_instr(W_MULC, a, 0, k));
+        row(a, 0, c, k);
+        return c;
+    }
+    uint32_t mul_constant(uint32_t a, uint32_t k) { return mul_constant_plain(a, k); }
     Instr take_origin(Mode mode, const Q4& v) {
         if (mode == CONSTANT) return mk_instr(W_CONST, 0, 0, v[0], v[1], v[2], v[3]);
         if (!have_hint) throw std::logic_error("witness without provenance");
@@ -112,7 +137,8 @@ struct ConstraintSystem {
     uint32_t new_m31(uint32_t v, Mode mode) {
         const Q4 q{v, 0, 0, 0};
         const uint32_t c = push(q, take_origin(mode, q));
-        n_rows++;
+        if (mode == WITNESS) row(c, 0, c, 1, 0, 1);
+        else row(1, 0, c, v);
         return c;
     }
     uint32_t new_qm31(const Q4& v, Mode mode) {
@@ -120,11 +146,11 @@ struct ConstraintSystem {
         if (mode == CONSTANT) {
             const uint32_t a0 = new_m31(v[0], CONSTANT), a1 = new_m31(v[1], CONSTANT), a2 = new_m31(v[2], CONSTANT), a3 = new_m31(v[3], CONSTANT);
             uint32_t t = mul(a1, 2);
-            add(a0, t);
+            const uint32_t a = add(a0, t);
             t = mul(a3, 2);
             t = add(a2, t);
-            mul(t, 3);
-            n_rows++;
+            const uint32_t b = mul(t, 3);
+            row(a, b, c, 1);
         }
         return c;
     }
@@ -157,7 +183,7 @@ inline Var mul(const Var& a0, const Var& b0) {
 inline Var mul_constant(const Var& a, uint32_t k) { return mk(a.cs, hq_scale(a.value, k % MP), a.cs->mul_constant(a.variable, k % MP), a.kind); }
 inline void equalverify(const Var& a, const Var& b) {
     if (a.value != b.value) throw std::runtime_error("equalverify: the template proof does not satisfy the circuit");
-    a.cs->insert_gate();
+    a.cs->insert_gate(a.variable, 0, b.variable, 1);
 }
 
 inline Var m31_zero(ConstraintSystem* cs) { return mk(cs, {0, 0, 0, 0}, 0, 1); }
@@ -177,7 +203,7 @@ inline Var m31_witness(ConstraintSystem* cs, uint32_t v, const Instr& hint) {
 }
 inline Var m31_inv(const Var& a) {
     Var res = m31_witness(a.cs, h_inv(a.value[0]), mk_instr(W_INV, a.variable));
-    a.cs->insert_gate();
+    a.cs->insert_gate(a.variable, res.variable, 1, 0);
     return res;
 }
 inline Var cm31_from_m31(const Var& real, const Var& imag) {
@@ -227,9 +253,9 @@ inline std::array<Var, 4> decompose_m31(const Var& a) {
                              m31_witness(cs, a.value[1], mk_instr(W_COORD, a.variable, 0, 1)),
                              m31_witness(cs, a.value[2], mk_instr(W_COORD, a.variable, 0, 2)),
                              m31_witness(cs, a.value[3], mk_instr(W_COORD, a.variable, 0, 3))};
-    cs->add(parts[0].variable, cs->mul(parts[1].variable, 2));
-    cs->mul(cs->add(parts[2].variable, cs->mul(parts[3].variable, 2)), 3);
-    cs->insert_gate();
+    const uint32_t l = cs->add(parts[0].variable, cs->mul(parts[1].variable, 2));
+    const uint32_t r = cs->mul(cs->add(parts[2].variable, cs->mul(parts[3].variable, 2)), 3);
+    cs->insert_gate(l, r, a.variable, 1);
     return parts;
 }
 inline std::array<Var, 2> decompose_cm31(const Var& a) {
@@ -240,7 +266,7 @@ inline std::array<Var, 2> decompose_cm31(const Var& a) {
 }
 inline Var qm31_inv(const Var& a) {
     Var res = qm31_witness(a.cs, hq_inv(a.value), mk_instr(W_QINV, a.variable));
-    a.cs->insert_gate();
+    a.cs->insert_gate(a.variable, res.variable, 1, 0);
     return res;
 }
 inline std::pair<Var, Var> swap(const Var& a, const Var& b, bool bit_value, uint32_t bit_variable) {

@@ -67,8 +67,8 @@ inline Bits bits_from_m31(const Var& v, size_t l) {
         res.value.push_back(b);
         res.variables.push_back(bit);
         const Var minus_one = m31_constant(cs, MP - 1);
-        cs->add(bit, minus_one.variable);
-        cs->insert_gate();
+        const uint32_t bit_minus_one = cs->add(bit, minus_one.variable);
+        cs->insert_gate(bit, bit_minus_one, 0, 0);
     }
     Var rec = mk(cs, {res.value[0], 0, 0, 0}, res.variables[0], 1);
     for (size_t i = 1; i < l; i++) {
@@ -79,7 +79,7 @@ inline Bits bits_from_m31(const Var& v, size_t l) {
     if (l == 31) {
         uint32_t product = cs->mul(res.variables[0], res.variables[1]);
         for (size_t i = 2; i < l; i++) product = cs->mul(product, res.variables[i]);
-        cs->enforce_zero();
+        cs->enforce_zero(product);
     }
     return res;
 }
@@ -163,7 +163,10 @@ struct Gadgets {
     Half swap_permute_get_rate(const Half& l, const Half& r, bool bit_value, uint32_t bit_variable) {
         return permute(l, r, false, true, true, bit_value, bit_variable).first;
     }
-    void half_equalverify(const Half&, const Half&) { cs->insert_gate(); cs->insert_gate(); }
+    void half_equalverify(const Half& a, const Half& b) {
+        cs->insert_gate(a.left, 0, b.left, 1);
+        cs->insert_gate(a.right, 0, b.right, 1);
+    }
 
     // ---- Merkle hasher (merkle/src/lib.rs)
     Half hash_tree_with_swap(const Half& l, const Half& r, bool bit_value, uint32_t bit_variable) { return swap_permute_get_rate(l, r, bit_value, bit_variable); }

@@ -102,6 +102,69 @@ def test_builder_writes_the_oracles_program_for_every_fixture_shape(rsv, manifes
     assert len(seen) >= 10
 
 
+def _oracle_rows(c):
+    return np.stack([np.array(x, dtype=np.int64) % 0x7FFFFFFF for x in (c.a_wire, c.b_wire, c.c_wire, c.op, c.poseidon_wire, c.enforce_c_m31)], axis=1)
+
+
+def test_gate_list_is_the_oracles(rsv, manifest):
+    """rsv_witness_program_gates: the Plonk rows the library's gadgets left (wires, op, Poseidon wire, enforce_c_m31) equal
+    the oracle's constraint system row for row on every fixture; and for ANOTHER proof of a shape the rows whose `op`
+    follows the witness (CirclePointM31Var::select), set from that proof's GPU variables, give that proof's own gate list."""
+    from oracle import recursion_circuit as rc
+    for e in manifest:
+        if e.get("expect") != "ok" or "struct" in e:
+            continue
+        name = e["file"]
+        wp = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name))
+        rows, ops = wp.gates()
+        c, _, _ = rc.build_circuit(read_proof(name), ob, _inputs(name))
+        assert np.array_equal(rows, _oracle_rows(c)), name
+        assert len(ops) > 0 and (rows[ops[:, 0], 1] == 0).all()
+        wp.close()
+    wp = rsv.WitnessProgram.build(read_proof("level10-1.bin"), fixture_cfg("level10-1.bin"))
+    variables, accept, _ = rsv.witness([read_proof("level11-1.bin")], wp)
+    template_rows, _ = wp.gates()
+    rows, _ = wp.gates(variables[0])
+    c, _, _ = rc.build_circuit(read_proof("level11-1.bin"), ob)
+    assert accept[0] == 1 and np.array_equal(rows, _oracle_rows(c)) and not np.array_equal(rows, template_rows)
+    wp.close()
+
+
+def test_everything_the_next_prover_reads_comes_out_of_the_library(rsv):
+    """generate_plonk_with_poseidon_circuit + populate_logup_arguments (plonk_with_poseidon.rs:345-629) fed with the library's
+    outputs ONLY — variables and flow from the GPU, gate list and flow wires from the built program — give the 22 Plonk
+    columns the next fixture proves (the oracle package is used for the padding / multiplicity / interpolation arithmetic,
+    not for a single value of the circuit)."""
+    from oracle import recursion_circuit as rc
+    from oracle.recursion_circuit import trace as T
+    pin = next(p for p in _pins() if p["src"] == "level11-1.bin")
+    orders = [tuple(tuple(x) for x in o) for o in pin["shift_orders"]]
+    walks = [(1 if o[0] == (-1, 0) else 0) | (2 if o[1] == (-1, 0) else 0) for o in orders]
+    src = pin["src"]
+    wp = rsv.WitnessProgram.build(read_proof("level10-1.bin"), fixture_cfg(src), set_walks=walks)  # another proof as the template
+    variables, accept, _, flow, swap = rsv.witness([read_proof(src)], wp, with_flow=True)
+    rows, _ = wp.gates(variables[0])
+    wires = wp.export().flow_wires
+    c = rc.cs.ConstraintSystem()
+    c.variables = [tuple(int(x) for x in v) for v in variables[0]]
+    c.a_wire, c.b_wire, c.c_wire, c.op, c.poseidon_wire, c.enforce_c_m31 = (rows[:, k].tolist() for k in range(6))
+    c.flow = [((int(w[0]), None), (int(w[1]), None), (int(w[2]), None), (int(w[3]), None), int(w[4]), bool(sw)) for w, sw in zip(wires, swap[0])]
+    c.check_arithmetics()
+    nxt = read_proof(pin["dst"])
+    tr = ob.transcript_raw(nxt)
+    oods = (tuple(int(x) for x in tr[20:24]), tuple(int(x) for x in tr[24:28]))
+    want = rc.parse_proof(nxt).sampled_values
+    lp = int(np.frombuffer(nxt[:4], np.uint32)[0])
+    assert accept[0] == 1 and T.pad(c) == 1 << lp
+    pre, trace = T.plonk_columns(c)
+    pe = T.PointEvaluator(lp, oods)
+    for k, name in enumerate(T.PREPROCESSED):
+        assert pe.eval(pre[name]) == want[0][k][0], name
+    for k in range(12):
+        assert pe.eval(trace[k]) == want[1][k][0], k
+    wp.close()
+
+
 def test_builder_follows_the_four_hashset_walks(rsv):
     """set_walks: for each of the four orders in which a run of the reference can walk its two HashSets (and a mix of
     them over three copies) the builder writes the program of the oracle's circuit under the same orders; the four programs
