@@ -443,6 +443,18 @@ struct WitnessProgram {
         check(rsv_witness_program_export(p.handle, nullptr, nullptr, &p.flow_wires[0][0]), "rsv_witness_program_export");
         return p;
     }
+    // the circuit's Plonk rows (a_wire, b_wire, c_wire, op, poseidon_wire, enforce_c_m31) for the proof whose `variables`
+    // are given (empty: the template's): built programs only
+    std::vector<std::array<uint32_t, 6>> gates(const std::vector<QM31>& variables = {}) const {
+        uint32_t n_rows = 0, n_ops = 0;
+        check(rsv_witness_program_gates(handle, &n_rows, &n_ops, nullptr, nullptr), "rsv_witness_program_gates");
+        std::vector<std::array<uint32_t, 6>> rows(n_rows);
+        std::vector<std::array<uint32_t, 3>> ops(n_ops);
+        check(rsv_witness_program_gates(handle, nullptr, nullptr, &rows[0][0], n_ops ? &ops[0][0] : nullptr), "rsv_witness_program_gates");
+        if (!variables.empty())
+            for (const auto& o : ops) rows[o[0]][3] = variables[o[1]][0] ? o[2] : 0u;  // CirclePointM31Var::select's op follows the bit
+        return rows;
+    }
     void save(const std::string& path) const {
         uint32_t n_levels = 0;
         check(rsv_witness_program_info(handle, nullptr, &n_levels, nullptr), "rsv_witness_program_info");

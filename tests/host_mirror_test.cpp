@@ -238,6 +238,17 @@ static void test_witness(const std::string& program_path, const std::vector<uint
     std::vector<uint8_t> a2, r2;
     auto vars2 = built.variables({l10, l11}, inputs, a2, r2);
     EXPECT(vars2[0] == vars[0] && vars2[1] == vars[1]);
+    // the gate list for each of the two proofs: the same wires, `op` differing where it follows the witness; every gate holds
+    const auto g10 = built.gates(vars[0]), g11 = built.gates(vars[1]);
+    EXPECT(g10.size() == g11.size() && g10 != g11);
+    const uint64_t P = 0x7fffffffull;
+    for (size_t i = 0; i < g11.size(); i++) {
+        EXPECT(g10[i][0] == g11[i][0] && g10[i][1] == g11[i][1] && g10[i][2] == g11[i][2] && g10[i][4] == g11[i][4] && g10[i][5] == g11[i][5]);
+        const auto &a = vars[1][g11[i][0]], &b = vars[1][g11[i][1]], &c = vars[1][g11[i][2]];
+        const uint64_t op = g11[i][3];
+        if (op == 1) { for (int k = 0; k < 4; k++) EXPECT((a[k] + (uint64_t)b[k]) % P == c[k]); }
+        else if (op > 1) { for (int k = 0; k < 4; k++) EXPECT(op * ((a[k] + (uint64_t)b[k]) % P) % P == c[k]); }
+    }
     built.save(program_path + ".copy");
     WitnessProgram again = WitnessProgram::load(program_path + ".copy");
     auto vars3 = again.variables({l11}, inputs, a2, r2);
