@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=1)
+    ap.add_argument("--no-split", action="store_true", help="skip the verifying-pass-only timing (for a kernel trace whose last step is a witness call)")
     ap.add_argument("--layout", choices=["by_proof", "by_variable"], default="by_proof",
                     help="by_variable: d_variables[variable][proof] as the level kernels write it (RSV_OPT_WITNESS_LAYOUT = 2): no transpose")
     args = ap.parse_args()
@@ -93,7 +94,7 @@ def main():
     want[tampered] = 0
     if not np.array_equal(acc, want):
         raise SystemExit("verdict mismatch")
-    hints_ms = timed(lambda: ctx.verify_hints(d_blob, d_off, n, d_acc, None, cfg, inputs, **hint))
+    hints_ms = 0.0 if args.no_split else timed(lambda: ctx.verify_hints(d_blob, d_off, n, d_acc, None, cfg, inputs, **hint))
     eval_ms = max(whole_ms - hints_ms, 1e-6)
     achieved = bytes_per_proof * n / (eval_ms * 1e-3) / 1e9
     print(json.dumps({
