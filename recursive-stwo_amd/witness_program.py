@@ -21,7 +21,7 @@ variable:
     FRI_COL   imm0 = tree, imm1 = query, imm2 = word        SinglePairMerkleProof self / sibling values (d_fri_cols)
 
 Instructions are sorted by dependency depth ("levels"): everything inside a level only reads variables of earlier levels,
-so the GPU runs one launch per level over (instructions of the level) x (proofs).  The hash chains cost no depth — the
+so the GPU runs one launch per level over (instructions of the level) x (proofs), and the narrow tail in one launch.  The hash chains cost no depth — the
 outputs of the Poseidon accelerator are hints read from the flow records — which leaves the arithmetic chains (the
 composition accumulator, the folds): 265 levels for 39 000 to 340 000 variables.
 """
