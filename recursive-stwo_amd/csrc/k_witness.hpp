@@ -121,6 +121,21 @@ __global__ __launch_bounds__(256) void k_witness_strip(WitnessArgs a, const uint
     }
 }
 
+// A handful of proofs (n <= 4: the reference's own use is ONE proof per recursion step): the WHOLE program in one launch.
+// One workgroup of 1 024 lanes = (1 024 / P2) instruction slots x P2 proofs, P2 = n rounded up to a power of two; a
+// level is a few rounds of slots, a workgroup barrier ends it.  265 barriers instead of 120 launches.
+__global__ __launch_bounds__(1024) void k_witness_small(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t n_levels,
+                                                        uint32_t log_p2) {
+    const uint32_t p = threadIdx.x & ((1u << log_p2) - 1u), slot = threadIdx.x >> log_p2, n_slots = 1024u >> log_p2;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t begin = level_offsets[l], end = level_offsets[l + 1];
+        if (p < a.n)
+            for (uint32_t i = begin + slot; i < end; i += n_slots) witness_exec(a, i, p);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // vars[variable][proof] -> out[proof][variable] (the reference's per-proof vector), 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void k_witness_transpose(const uint4* __restrict__ vars, uint4* __restrict__ out, uint32_t n_vars,
                                                            uint32_t n) {
