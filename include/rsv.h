@@ -148,7 +148,7 @@ typedef enum rsv_option {
     RSV_OPT_WS_BUDGET_MB = 8,     /* 1 .. 2^20: budget of the per-query workspace (default 8192); larger batches are cut into groups */
     RSV_OPT_PERM_WG_PER_CU = 9,   /* 1 .. 8: grid of the persistent rsv_poseidon2_permute kernel (default 8) */
     RSV_OPT_HOST_CHUNK_MB = 10,   /* 1 .. 16384: staging chunk of rsv_verify_batch_host (default 256) */
-    RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 8), else 1 .. 64 gather threads of rsv_verify_batch_host */
+    RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 4), else 1 .. 64 gather threads of rsv_verify_batch_host */
     RSV_OPT_DEBUG_LOG = 12,       /* 0 / 1: print failing HIP calls to stderr (process-wide, ctx ignored) */
     RSV_OPT_CRITICAL_CHAIN = 13,  /* 0 auto, 1 the step's chain of dependent kernels on one stream, 2 the two-stream layout */
     RSV_OPT_DEVICE_ORDER = 14,    /* 0 / 1 batches under one configuration: slot order by shape on the device, no host round
@@ -315,7 +315,8 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
 /* Proofs that start in HOST memory, as the reference's callers hold them: one serialized buffer per proof
  * (bincode::serialize(&proof) -> Vec<u8>, examples/multi-proofs/src/main.rs:69-139).  Chunks of about
  * RSV_OPT_HOST_CHUNK_MB (default 256) MB are gathered into pinned staging memory by worker threads
- * (RSV_OPT_HOST_THREADS, default min(cores, 8)), uploaded by the DMA engine and verified, the three stages overlapping;
+ * (RSV_OPT_HOST_THREADS, default min(cores, 4)), uploaded by the DMA engine and verified, the three stages overlapping
+ * (a job below eight such chunks is cut into eight, none under 32 MB, so that the pipeline has something to overlap);
  * accept / reason are host arrays of n bytes.  Blocks until every verdict is written.  A buffer whose length is not a
  * multiple of 4 (every proof of this type is a whole number of 32-bit words) or exceeds 32 MB (a well-formed proof is
  * below 8 MB) is not uploaded and gets RSV_R_PARSE, like any other malformed proof. */

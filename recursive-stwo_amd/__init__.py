@@ -650,6 +650,18 @@ def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inne
     return sib, cols, accept, reason
 
 
+class HostBatch:
+    """The argument of rsv_verify_batch_host as a Rust caller holds it (a Vec of serialized proofs = pointers + lengths): built
+    once from a list of bytes / numpy uint8 buffers, which it keeps alive."""
+
+    def __init__(self, proofs):
+        self.keep = [np.frombuffer(p, dtype=np.uint8) if not isinstance(p, np.ndarray) else p for p in proofs]
+        self.n = len(self.keep)
+        self.ptrs = (ctypes.c_void_p * max(self.n, 1))(*[k.ctypes.data for k in self.keep])
+        self.lens = np.array([k.size for k in self.keep], dtype=np.uint64)
+        self.bytes = int(self.lens.sum())
+
+
 class Context:
     """One HIP stream + reusable HBM workspace on one device (rsv_ctx).  Operates on torch tensors that
     already live on that device; nothing is copied through the host.
@@ -759,17 +771,15 @@ class Context:
                                        d_reason.data_ptr() if d_reason is not None else None), "rsv_trace_paths_dev")
 
     def verify_batch_host(self, proofs, cfg, inputs=STANDARD_INPUTS):
-        """Proofs in host memory, one buffer each (bytes / numpy uint8 arrays): gather, upload and verify overlap
-        (rsv_verify_batch_host).  Returns (accept, reason) numpy arrays."""
-        n = len(proofs)
-        keep = [np.frombuffer(p, dtype=np.uint8) if not isinstance(p, np.ndarray) else p for p in proofs]
-        ptrs = (ctypes.c_void_p * max(n, 1))(*[k.ctypes.data for k in keep])
-        lens = np.array([k.size for k in keep], dtype=np.uint64)
+        """Proofs in host memory, one buffer each (bytes / numpy uint8 arrays, or a HostBatch that holds the pointer table of
+        such a list already): gather, upload and verify overlap (rsv_verify_batch_host).  Returns (accept, reason) numpy arrays."""
+        hb = proofs if isinstance(proofs, HostBatch) else HostBatch(proofs)
+        n = hb.n
         accept = np.zeros(n, np.uint8)
         reason = np.zeros(n, np.uint8)
         pi = make_inputs(inputs)
         pc = prepare_cfg(cfg, n)  # host residency: the library uploads the per-proof index chunk by chunk
-        _check(lib.rsv_verify_batch_host(self._h, ptrs, lens.ctypes.data_as(_u64p), n, pc.ref(), pi, len(list(inputs)),
+        _check(lib.rsv_verify_batch_host(self._h, hb.ptrs, hb.lens.ctypes.data_as(_u64p), n, pc.ref(), pi, len(list(inputs)),
                                          accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p)), "rsv_verify_batch_host")
         return accept, reason
 

@@ -106,6 +106,14 @@ __global__ __launch_bounds__(256) void k_witness_level(WitnessArgs a) {
     witness_exec(a, i, p);
 }
 
+// the same for batches of at least a wave of proofs: blockIdx.y = the instruction, so that the instruction words are scalar
+// loads and the switch a scalar branch (in the 1-D form a wave may straddle two instructions, and every lane divides)
+__global__ __launch_bounds__(256) void k_witness_level_wide(WitnessArgs a) {
+    const uint32_t i = a.begin + blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    witness_exec(a, i, p);
+}
+
 // The narrow tail of a program (the Poseidon AIR's accumulator chain: ~125 levels of 1 .. 28 instructions) in ONE launch:
 // dependencies never cross proofs, so a workgroup that owns 64 proofs can walk the levels on its own — its four waves
 // share a level's instructions, a workgroup barrier separates levels (the waves of a workgroup share the CU's L1, so what

@@ -40,7 +40,7 @@ struct Options {
     long long ws_budget_mb = 8192;
     int perm_wg_per_cu = 8;
     long long host_chunk_mb = 256;
-    int host_threads = 0;      // 0 = min(cores, 8)
+    int host_threads = 0;      // 0 = min(cores, 4)
     int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
     int device_order = 0;      // 0 / 1 single-configuration batches: slot order on the device, no host round trip; 2 host
     int graph = 0;             // 0 / 2 off, 1 replay repeated identical calls as a HIP graph (experiment)
