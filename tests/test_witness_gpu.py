@@ -339,6 +339,22 @@ def test_build_refuses_what_is_not_a_template(rsv):
         assert e.value.code == code
 
 
+def test_witness_of_a_ragged_large_batch(rsv):
+    """n = 600 (three 256-lane blocks per instruction, the last one ragged; a tampered proof in the middle): EVERY row of
+    both output layouts against the gadgets' vector."""
+    name = "level12-1.bin"
+    wp = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name))
+    want, _, _ = _oracle_variables(name)
+    n, bad = 600, 311
+    batch = [read_proof(name)] * n
+    batch[bad] = ob.tamper(read_proof(name), 3)
+    good = np.arange(n) != bad
+    variables, accept, reason = rsv.witness(batch, wp, _inputs(name))[:3]
+    assert accept.tolist() == good.astype(int).tolist() and reason[bad] != 0
+    assert (variables[good] == want[None]).all()
+    wp.close()
+
+
 def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
     """Context.witness on tensors in HBM (n = 96 copies, two calls on one context: the second reuses the scratch), and the
     API errors: a configuration that is not the program's, a misaligned output."""
