@@ -156,9 +156,13 @@ typedef enum rsv_option {
     RSV_OPT_GRAPH = 15,           /* 0 / 2 off; 1 (experiment) a call repeated with identical arguments — same buffers, sizes,
                                      configuration, public inputs — is captured into a HIP graph on its second sighting
                                      and replayed afterwards; rsv_last_stage_times then reports the last plain call */
-    RSV_OPT_WITNESS_LAYOUT = 16   /* rsv_witness_eval_dev's d_variables: 0 / 1 [proof][variable] (the reference's vector per
+    RSV_OPT_WITNESS_LAYOUT = 16,  /* rsv_witness_eval_dev's d_variables: 0 / 1 [proof][variable] (the reference's vector per
                                      proof); 2 [variable][proof] — what the level kernels write: no transpose (a third of
                                      the traffic) and no second copy in scratch, for consumers that gather for many proofs */
+    RSV_OPT_WITNESS_SMALL_MAX = 17, /* rsv_witness_eval_dev: 0 default (by batch and program size), else 1 + the largest batch whose
+                                     program runs in ONE launch (a workgroup per few proofs walks all levels) instead of one
+                                     launch per level; 1 = never */
+    RSV_OPT_WITNESS_SMALL_LOG = 18  /* 0 default, else 1 + log2(proofs per workgroup) of that form, 1 .. 7 */
 } rsv_option;
 int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 

@@ -38,15 +38,14 @@ __device__ __forceinline__ QM31 q_of(uint4 v) { return q_mk(v.x, v.y, v.z, v.w);
 __device__ __forceinline__ uint4 u4_of(QM31 q) { return make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); }
 __device__ __forceinline__ uint4 u4_words(const uint32_t* w) { return make_uint4(w[0], w[1], w[2], w[3]); }
 
-// one instruction for one proof
-__device__ __forceinline__ void witness_exec(const WitnessArgs& a, uint32_t i, uint32_t p) {
-    const uint32_t* in = a.instr + (size_t)i * 8;
-    const uint32_t op = in[0], dst = in[1], x = in[2], y = in[3], i0 = in[4], i1 = in[5], i2 = in[6];
+// one instruction (its eight words: w0 = op, dst, a, b; w1 = imm0..3) for one proof
+__device__ __forceinline__ void witness_exec(const WitnessArgs& a, const uint4 w0, const uint4 w1, uint32_t p) {
+    const uint32_t op = w0.x, dst = w0.y, x = w0.z, y = w0.w, i0 = w1.x, i1 = w1.y, i2 = w1.z;
     const size_t n = a.n;
     uint4 r = make_uint4(0, 0, 0, 0);
     const bool ok = a.accept[p] != 0;  // a rejected proof's sections may not be where the program expects them
     switch (op) {
-    case W_CONST: r = make_uint4(i0, i1, i2, in[7]); break;
+    case W_CONST: r = w1; break;
     case W_ADD: r = u4_of(q_add(q_of(a.vars[x * n + p]), q_of(a.vars[y * n + p]))); break;
     case W_MUL: r = u4_of(q_mul(q_of(a.vars[x * n + p]), q_of(a.vars[y * n + p]))); break;
     case W_MULC: r = u4_of(q_mul_m(q_of(a.vars[x * n + p]), i0)); break;
@@ -97,6 +96,10 @@ __device__ __forceinline__ void witness_exec(const WitnessArgs& a, uint32_t i, u
     }
     a.vars[dst * n + p] = r;
 }
+__device__ __forceinline__ void witness_exec(const WitnessArgs& a, uint32_t i, uint32_t p) {
+    const uint4* in = reinterpret_cast<const uint4*>(a.instr) + (size_t)i * 2;
+    witness_exec(a, in[0], in[1], p);
+}
 
 // one level, grid = (instructions of the level) x (proofs)
 __global__ __launch_bounds__(256) void k_witness_level(WitnessArgs a) {
@@ -114,34 +117,40 @@ __global__ __launch_bounds__(256) void k_witness_level_wide(WitnessArgs a) {
     witness_exec(a, i, p);
 }
 
-// The narrow tail of a program (the Poseidon AIR's accumulator chain: ~125 levels of 1 .. 28 instructions) in ONE launch:
-// dependencies never cross proofs, so a workgroup that owns 64 proofs can walk the levels on its own — its four waves
-// share a level's instructions, a workgroup barrier separates levels (the waves of a workgroup share the CU's L1, so what
-// one wave stored is what the next level's loads see).
-__global__ __launch_bounds__(256) void k_witness_strip(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t l0, uint32_t l1) {
-    const uint32_t p = blockIdx.x * 64 + (threadIdx.x & 63u), wv = threadIdx.x >> 6;
+// Levels l0 .. l1 walked by ONE workgroup for its own proofs (dependencies never cross proofs): instruction slot `slot` of
+// `n_slots` takes instructions begin + slot, + n_slots, ... of every level, a workgroup barrier ends a level (the waves of
+// a workgroup share the CU's L1, so what one wave stored is what the next level's loads see).  A level costs about one
+// memory round trip (the operands): reading the bounds and instruction words a level ahead was measured and gains nothing.
+__device__ __forceinline__ void witness_walk(const WitnessArgs& a, const uint32_t* __restrict__ level_offsets, uint32_t l0, uint32_t l1,
+                                             uint32_t p, uint32_t slot, uint32_t n_slots) {
     for (uint32_t l = l0; l < l1; l++) {
-        const uint32_t begin = level_offsets[l], end = level_offsets[l + 1];
-        if (p < a.n)
-            for (uint32_t i = begin + wv; i < end; i += 4) witness_exec(a, i, p);
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
-// A handful of proofs (n <= 4: the reference's own use is ONE proof per recursion step): the WHOLE program in one launch.
-// One workgroup of 1 024 lanes = (1 024 / P2) instruction slots x P2 proofs, P2 = n rounded up to a power of two; a
-// level is a few rounds of slots, a workgroup barrier ends it.  265 barriers instead of 120 launches.
-__global__ __launch_bounds__(1024) void k_witness_small(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t n_levels,
-                                                        uint32_t log_p2) {
-    const uint32_t p = threadIdx.x & ((1u << log_p2) - 1u), slot = threadIdx.x >> log_p2, n_slots = 1024u >> log_p2;
-    for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t begin = level_offsets[l], end = level_offsets[l + 1];
         if (p < a.n)
             for (uint32_t i = begin + slot; i < end; i += n_slots) witness_exec(a, i, p);
         __threadfence_block();
         __syncthreads();
     }
+}
+
+// The narrow tail of a program (the Poseidon AIR's accumulator chain: ~125 levels of 1 .. 28 instructions) in ONE launch:
+// dependencies never cross proofs, so a workgroup that owns 64 proofs can walk the levels on its own — its four waves
+// share a level's instructions, a workgroup barrier separates levels (the waves of a workgroup share the CU's L1, so what
+// one wave stored is what the next level's loads see).
+__global__ __launch_bounds__(256) void k_witness_strip(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t l0, uint32_t l1) {
+    const uint32_t p = blockIdx.x * 64 + (threadIdx.x & 63u), wv = threadIdx.x >> 6;
+    witness_walk(a, level_offsets, l0, l1, p, wv, 4u);
+}
+
+// Small and medium batches: the WHOLE program in one launch.  A workgroup of 1 024 lanes owns P2 = 2^log_p2 proofs (n <= 4:
+// one workgroup, P2 = n rounded up — the reference's own use is ONE proof per recursion step; larger batches: P2 proofs per
+// workgroup, n / P2 workgroups side by side — dependencies never cross proofs) and walks the levels on its own:
+// (1 024 / P2) instruction slots x P2 proofs, a level is a few rounds of slots, a workgroup barrier ends it.  265 barriers
+// instead of 140 launches with a machine-wide drain between them; the price is narrower rows (P2 x 16 B per instruction
+// instead of 1 KB), which is why the level-per-launch form takes over for large batches (witness_api.inc).
+__global__ __launch_bounds__(1024) void k_witness_small(WitnessArgs a, const uint32_t* __restrict__ level_offsets, uint32_t n_levels,
+                                                        uint32_t log_p2) {
+    const uint32_t p = (blockIdx.x << log_p2) + (threadIdx.x & ((1u << log_p2) - 1u));
+    witness_walk(a, level_offsets, 0, n_levels, p, threadIdx.x >> log_p2, 1024u >> log_p2);
 }
 
 // vars[variable][proof] -> out[proof][variable] (the reference's per-proof vector), 32 x 32 tiles through LDS

@@ -355,6 +355,37 @@ def test_witness_of_a_ragged_large_batch(rsv):
     wp.close()
 
 
+def test_witness_launch_forms_agree(rsv):
+    """The level-per-launch form and the one-launch form (a workgroup per 1, 4, 64 proofs), forced through
+    RSV_OPT_WITNESS_SMALL_MAX / _LOG on batches of 3 and 70 proofs with a tampered one: the same rows as the gadgets'."""
+    import torch
+    name = "level12-1.bin"
+    wp = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name))
+    want, _, _ = _oracle_variables(name)
+    dev = torch.device("cuda:0")
+    ctx = rsv.Context(0)
+    for n, bad in ((3, 1), (70, 41)):
+        batch = [read_proof(name)] * n
+        batch[bad] = ob.tamper(read_proof(name), 5)
+        blob, offsets = rsv.pack(batch)
+        d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        good = np.arange(n) != bad
+        for small_max, small_log in ((1, 0), (n + 1, 1), (n + 1, 3), (n + 1, 7), (0, 0)):
+            ctx.set_option("witness_small_max", small_max)
+            ctx.set_option("witness_small_log", small_log)
+            d_vars = torch.full((n, wp.n_vars, 4), -1, dtype=torch.int32, device=dev)
+            d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+            ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(name))
+            ctx.synchronize()
+            assert d_acc.cpu().numpy().tolist() == good.astype(int).tolist(), (n, small_max, small_log)
+            assert (d_vars.cpu().numpy().view(np.uint32)[good] == want[None]).all(), (n, small_max, small_log)
+    for opt, v in (("witness_small_max", (1 << 20) + 2), ("witness_small_log", 8), ("witness_small_max", -1)):
+        with pytest.raises(rsv.RsvError):
+            ctx.set_option(opt, v)
+    ctx.close()
+    wp.close()
+
+
 def test_witness_on_device_buffers_and_a_wrong_configuration(rsv):
     """Context.witness on tensors in HBM (n = 96 copies, two calls on one context: the second reuses the scratch), and the
     API errors: a configuration that is not the program's, a misaligned output."""

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=1)
     ap.add_argument("--no-split", action="store_true", help="skip the verifying-pass-only timing (for a kernel trace whose last step is a witness call)")
+    ap.add_argument("--small-max", type=int, default=0, help="RSV_OPT_WITNESS_SMALL_MAX (0 = the library's default)")
+    ap.add_argument("--small-log", type=int, default=0, help="RSV_OPT_WITNESS_SMALL_LOG (0 = the library's default)")
     ap.add_argument("--layout", choices=["by_proof", "by_variable"], default="by_proof",
                     help="by_variable: d_variables[variable][proof] as the level kernels write it (RSV_OPT_WITNESS_LAYOUT = 2): no transpose")
     args = ap.parse_args()
@@ -67,6 +69,8 @@ def main():
     d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
     ctx = rsv.Context(0)
     ctx.set_option("witness_layout", args.layout)
+    ctx.set_option("witness_small_max", args.small_max)
+    ctx.set_option("witness_small_log", args.small_log)
     s = prog.shape
     M = max(s["lp"] + 1, s["lq"] + 2) + s["blowup"]
     hint = dict(shape=(s["nq"], M, s["n_inner"]),
