@@ -15,7 +15,7 @@ timeout -k 10 250 python tools/bench_witness.py --fixture level10-1.bin --proofs
 timeout -k 10 250 python tools/bench_witness.py --fixture level1-5.bin --proofs 1024 > $OUT/witness_level1_1024.json 2> $OUT/witness.err || tail -3 $OUT/witness.err
 timeout -k 10 250 python tools/bench_witness.py --fixture recursive_proof_16_15.bin --copies 5 --proofs 1024 > $OUT/witness_rec16_x5_1024.json 2> $OUT/witness.err || tail -3 $OUT/witness.err
 (cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/witness_kt -o kt -- python3 $OLDPWD/tools/bench_witness.py --fixture level10-1.bin --proofs 4096 --steps 2 > $OLDPWD/$OUT/witness_under_rocprof.json 2> $OLDPWD/$OUT/witness_kt.err); find $OUT/witness_kt -name "*kernel_trace.csv" -size +8M -delete; echo witness done
-timeout -k 10 300 python tests/perm_census.py > $OUT/perm_census.txt 2>&1; echo census done
+timeout -k 10 300 python tests/perm_census.py > $OUT/perm_census.txt 2>&1 && echo census done || { echo "census FAILED"; tail -3 $OUT/perm_census.txt; }
 timeout -k 10 300 python tests/soak.py 1500 31 - single 300 > $OUT/soak.txt 2>&1; tail -2 $OUT/soak.txt
 timeout -k 10 300 python tests/soak.py 1500 32 pow0 >> $OUT/soak.txt 2>&1; tail -1 $OUT/soak.txt
 python3 - <<'PY'
