@@ -162,7 +162,9 @@ typedef enum rsv_option {
     RSV_OPT_WITNESS_SMALL_MAX = 17, /* rsv_witness_eval_dev: 0 default (by batch and program size), else 1 + the largest batch whose
                                      program runs in ONE launch (a workgroup per few proofs walks all levels) instead of one
                                      launch per level; 1 = never */
-    RSV_OPT_WITNESS_SMALL_LOG = 18  /* 0 default, else 1 + log2(proofs per workgroup) of that form, 1 .. 7 */
+    RSV_OPT_WITNESS_SMALL_LOG = 18, /* 0 default, else 1 + log2(proofs per workgroup) of that form, 1 .. 7 */
+    RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
+                                     kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;
 int rsv_ctx_set_option(rsv_ctx* ctx, int option, long long value);
 

@@ -94,6 +94,11 @@ struct MerkleArgs {
     //   pair_cols[(((slot*(1+maxInner) + s)*G + i)*3 + c]     c-th data level from the top: self | sibling value, 8 words
     uint32_t* pair_sib;
     uint32_t* pair_cols;
+    // top of the cap in a kernel of its own (k_cap_top): the in-kernel cap stops at level Lt (0 = it walks to the root) and
+    // leaves, per (slot, tree), the present nodes of that level and their presence mask:
+    //   capn[((slot * T + tree) << Lt) + pos][8], capm[slot * T + tree]    T = 4 (trace trees: t*) / 1 + maxInner (FRI trees: p*)
+    uint32_t Lt;
+    uint32_t *tcapn, *tcapm, *pcapn, *pcapm;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -117,7 +122,9 @@ struct CapGroup {
 template <int BLOCK>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
-                                           const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0) {
+                                           const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0, uint32_t Lt = 0,
+                                           uint32_t* capn = nullptr, uint32_t* capm = nullptr, uint32_t slot0 = 0, uint32_t n_slots = 0,
+                                           uint32_t T = 0, uint32_t ti = 0) {
     const uint32_t t = threadIdx.x;
     __syncthreads();  // xch is free, descriptors written
     if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
@@ -128,7 +135,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
     }
     __syncthreads();
     uint32_t bufi = 0;
-    for (uint32_t l = Lc; l-- > 0;) {  // parent level
+    for (uint32_t l = Lc; l-- > Lt;) {  // parent level
         if (emit && live) {
             // the query's ancestor at child level l + 1 and its sibling: a present node (LDS) or the witness entry
             // its parent consumes (same rank as below)
@@ -183,6 +190,16 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
         if (t < per_block) mask[bufi][t] = 0;
         bufi ^= 1;
         __syncthreads();
+    }
+    if (Lt && ti < T) {  // the levels above Lt belong to k_cap_top: hand over this level's nodes (xch[bufi], mask[bufi]);
+                         // ti >= T: a launch's grid covers the deepest bucket's FRI layers, this bucket has fewer trees
+        const uint32_t g2 = t >> Lt, pp = t & ((1u << Lt) - 1u);
+        if (g2 < per_block && slot0 + g2 < n_slots) {
+            const uint32_t cm = grp_desc[g2].active ? (uint32_t)mask[bufi][g2] : 0u;
+            const size_t idx = (size_t)(slot0 + g2) * T + ti;
+            if (pp == 0) capm[idx] = cm;
+            if ((cm >> pp) & 1u) store_hash(capn + ((idx << Lt) + pp) * 8, load_hash(&xch[bufi][(g2 << Lt) + pp][0]));
+        }
     }
 }
 
@@ -342,7 +359,8 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
     }
     if (Lc) {
         uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
-        merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u);
+        merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
+                          a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t);
     }
 }
 
@@ -532,7 +550,94 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
         const uint32_t fl = (ok ? 0u : 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER)) | ((bad || want_hw != L->hash_n) ? F_RESCAN : 0u);
         if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
-    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u);
+    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
+                              a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot);
+}
+
+// ---------------------------------------------------------------- k_cap_top
+// The last levels of every tree, ONE LANE PER (slot, tree).  Inside the Merkle kernels the top levels of the cap keep
+// few lanes busy — 16 proofs x 2 and x 1 node positions are a half and a quarter of one wave, each at the price of a
+// full wave-level permutation — and that is 8 of the 20 permutation slots per tree the cap costs a 16-query proof.  Here
+// a wave carries 64 trees and 2^Lt - 1 sequential node hashes each (3 for Lt = 2, 7 for Lt = 3): the same nodes in 3
+// (7) slots per tree.  Same walk as merkle_cap (same witness ranks, same flags), nodes in registers.
+struct CapTopIndex {
+    uint32_t first_block[MAX_FUSED + 1];  // blocks of 256 (slot, tree) items per argument set
+};
+
+static_assert(sizeof(Fused<MerkleArgs>) + sizeof(CapTopIndex) + 8 <= 4096 && sizeof(Fused<MerkleArgs>) + sizeof(FlowArgs) <= 4096,
+              "kernel arguments are limited to 4 KB");
+
+template <int LT>
+__device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_, uint32_t ti, bool pair) {
+    const uint32_t T = pair ? 1u + a.maxInner : 4u;
+    const size_t idx = (size_t)slot_ * T + ti;
+    uint32_t mask = (pair ? a.pcapm : a.tcapm)[idx];
+    if (!mask) return;  // a rejected proof, or a tree this proof does not have
+    const uint32_t* capn = (pair ? a.pcapn : a.tcapn) + (idx << LT) * 8;
+    const uint32_t p = a.pl.proof_of(slot_);
+    const ProofMeta& m = a.metas[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+    const PlanHdr& h = a.pl.hdr[slot_];
+    const uint32_t *hw, *root;
+    const uint16_t* wf = nullptr;
+    uint32_t hw_n, s_top, fail_bit;
+    if (pair) {
+        const FriLayerRef& L = ti == 0 ? m.first : m.inner[ti - 1];
+        const uint32_t top = ti == 0 ? m.M : m.M - ti;
+        hw = w + L.hash_off; hw_n = L.hash_n; wf = ti == 0 ? h.wf : nullptr; s_top = lvl_s(h.lvl[top]);
+        root = w + L.commit_off; fail_bit = ti == 0 ? R_FRI_FIRST : R_FRI_INNER;
+    } else {
+        const uint32_t mx = (ti == 3) ? m.M : umax(m.A, m.B);
+        hw = w + m.hw_off[ti]; hw_n = m.hw_n[ti]; s_top = lvl_s(h.lvl[mx + 1]);
+        root = w + W_COMMIT0 + 8 * ti; fail_bit = R_MERKLE_T0 + ti;
+    }
+    uint32_t* flags = &a.ctxs[p].flags;
+    Hash8 node[1 << LT];
+#pragma unroll
+    for (int k = 0; k < (1 << LT); k++) node[k] = ((mask >> k) & 1u) ? load_hash(capn + 8 * k) : zero8();
+#pragma unroll
+    for (int l = LT - 1; l >= 0; l--) {  // parent level
+        const uint32_t lack = (mask ^ (mask >> 1)) & 0x55555555u;  // bit 2p': exactly one child present
+        const uint32_t base = wf ? (uint32_t)wf[l + 1] : lvl_s(h.lvl[l + 2]) - s_top;
+        uint32_t next = 0;
+#pragma unroll
+        for (int pp = 0; pp < (1 << l); pp++) {
+            const uint32_t pres = (mask >> (2 * pp)) & 3u;
+            if (pres) {
+                Hash8 left = node[2 * pp], right = node[2 * pp + 1];
+                bool bad = false;
+                if (pres != 3u) {
+                    const uint32_t wi = base + (uint32_t)__popc(lack & ((1u << (2 * pp)) - 1u));
+                    Hash8 w8 = zero8();
+                    if (wi < hw_n) {
+                        w8 = load_hash(hw + 8 * wi);
+                        if (hash_over(w8)) atomicOr(flags, 1u << R_PARSE);
+                    } else bad = true;
+                    if (!(pres & 1u)) left = w8;
+                    if (!(pres & 2u)) right = w8;
+                }
+                node[pp] = hash_tree(left, right);
+                if (l == 0) {
+                    if (bad || !hash_eq(node[0], load_hash(root))) atomicOr(flags, (1u << fail_bit) | (bad ? F_RESCAN : 0u));
+                } else if (bad) atomicOr(flags, (1u << fail_bit) | F_RESCAN);
+                next |= 1u << pp;
+            }
+        }
+        mask = next;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
+    RSV_TAG(pair ? 4 : 3);
+    uint32_t k = 0;
+    while (k + 1 < f.nb && blockIdx.x >= ix.first_block[k + 1]) k++;
+    const MerkleArgs& a = f.a[k];
+    const uint32_t T = pair ? 1u + a.maxInner : 4u;
+    const uint64_t item = (uint64_t)(blockIdx.x - ix.first_block[k]) * 256 + threadIdx.x;
+    if (!a.Lt || item >= (uint64_t)a.n * T) return;
+    const uint32_t slot_ = (uint32_t)(item / T), ti = (uint32_t)(item % T);
+    if (a.Lt == 2) cap_top_walk<2>(a, slot_, ti, pair != 0);
+    else cap_top_walk<3>(a, slot_, ti, pair != 0);
 }
 
 }  // namespace rsv

@@ -510,9 +510,17 @@ def test_cap_disabled_matches_cap_enabled(rsv, knobs):
     knobs.set("tree_cap", "off")
     a0, r0 = rsv.verify_batch(batch, cfgs)
     knobs.set("tree_cap", "on")
+    knobs.set("cap_top", "off")
     a1, r1 = rsv.verify_batch(batch, cfgs)
     assert a0.tolist() == a1.tolist() and r0.tolist() == r1.tolist()
     assert a1[-3:].tolist() == [1, 1, 1]
+    # the last levels of every tree in k_cap_top (what batches of >= 8 192 proofs run): Lt = 2 for the 16- and 8-query
+    # proofs, 3 for the 80-query one; the oracle's verdicts for the tampered copies
+    knobs.set("cap_top", "on")
+    a2, r2 = rsv.verify_batch(batch, cfgs)
+    assert a0.tolist() == a2.tolist() and r0.tolist() == r2.tolist()
+    wa, wr = ob.verify_batch(batch, cfgs)
+    assert a2.tolist() == wa.tolist() and r2.tolist() == wr.tolist()
 
 
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])
