@@ -81,6 +81,9 @@ __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     __shared__ uint32_t xq[BLOCK][4];
+    // The FRI trees wait for this kernel while it shares the machine with the trace trees: its waves go first in the
+    // SIMDs' arbitration, so that it is over in a fraction of the trace trees' time and the FRI trees start beside them.
+    __builtin_amdgcn_s_setprio(3);
     RSV_FUSED_SELECT(f, a, bx);
     const uint32_t G = a.pl.G, per_block = BLOCK / G;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;

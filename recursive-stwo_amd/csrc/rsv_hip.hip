@@ -155,7 +155,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     c->device = device;
     c->opt = default_options();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, -1) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
