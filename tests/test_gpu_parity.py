@@ -505,8 +505,13 @@ def test_chunked_workspace_matches_unchunked(rsv):
 def test_cap_disabled_matches_cap_enabled(rsv, knobs):
     """tree_cap = off walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
     proof = read_proof("recursive_proof_16_15.bin")
-    batch = [ob.tamper(proof, i) for i in range(48)] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
-    cfgs = [fixture_cfg("recursive_proof_16_15.bin")] * 49 + [fixture_cfg("level1-5.bin"), fixture_cfg("level12-1.bin")]
+    # several proofs per bucket, buckets with fewer FRI layers than the launch's deepest one (their slots' cap nodes must
+    # not be touched by the grid rows of layers they do not have), tampered copies of every shape
+    extra = ["level12-1.bin", "level1-5.bin", "level12-1.bin", "level9-1.bin", "level12-1.bin", "level2-1.bin", "level9-1.bin"]
+    batch = [ob.tamper(proof, i) for i in range(48)] + [ob.tamper(read_proof(f), 3 + k) for k, f in enumerate(extra)] + \
+            [read_proof(f) for f in extra] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
+    cfgs = [fixture_cfg("recursive_proof_16_15.bin")] * 48 + [fixture_cfg(f) for f in extra] * 2 + \
+           [fixture_cfg("recursive_proof_16_15.bin"), fixture_cfg("level1-5.bin"), fixture_cfg("level12-1.bin")]
     knobs.set("tree_cap", "off")
     a0, r0 = rsv.verify_batch(batch, cfgs)
     knobs.set("tree_cap", "on")
