@@ -506,7 +506,8 @@ def test_cap_disabled_matches_cap_enabled(rsv, knobs):
     """tree_cap = off walks every path to the root; the dense top-of-tree cap must give identical verdicts."""
     proof = read_proof("recursive_proof_16_15.bin")
     # several proofs per bucket, buckets with fewer FRI layers than the launch's deepest one (their slots' cap nodes must
-    # not be touched by the grid rows of layers they do not have), tampered copies of every shape
+    # not be touched by the grid rows of layers they do not have — a violation shows only at scale, when such rows run after
+    # the rightful ones: the 53 248-proof chain of tests/test_full_size_parity.py caught it), tampered copies of every shape
     extra = ["level12-1.bin", "level1-5.bin", "level12-1.bin", "level9-1.bin", "level12-1.bin", "level2-1.bin", "level9-1.bin"]
     batch = [ob.tamper(proof, i) for i in range(48)] + [ob.tamper(read_proof(f), 3 + k) for k, f in enumerate(extra)] + \
             [read_proof(f) for f in extra] + [proof, read_proof("level1-5.bin"), read_proof("level12-1.bin")]
