@@ -154,8 +154,18 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     if (!c) return RSV_E_DEVICE;
     c->device = device;
     c->opt = default_options();
+    // The side stream carries the kernels another stage waits for while they share the machine with a wider one (k_query
+    // beside the trace trees): one dispatch priority level above normal where the device has one, a plain stream otherwise.
+    auto create_side = [](hipStream_t* s) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest <= -1 &&
+            hipStreamCreateWithPriority(s, hipStreamNonBlocking, -1) == hipSuccess)
+            return hipSuccess;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, -1) != hipSuccess ||
+        create_side(&c->side) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
