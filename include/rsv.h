@@ -163,6 +163,8 @@ typedef enum rsv_option {
                                      program runs in ONE launch (a workgroup per few proofs walks all levels) instead of one
                                      launch per level; 1 = never */
     RSV_OPT_WITNESS_SMALL_LOG = 18, /* 0 default, else 1 + log2(proofs per workgroup) of that form, 1 .. 7 */
+    RSV_OPT_WITNESS_WALK_LOG = 20, /* rsv_witness_eval_dev, batches that run the program level by level: the levels behind the
+                                     program's wide head in ONE launch, a workgroup per 2^k proofs: 0 auto, 1 off, else 1 + k (k = 1 .. 6) */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

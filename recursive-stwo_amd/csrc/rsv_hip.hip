@@ -48,6 +48,7 @@ struct Options {
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
     int witness_small_log = 0;        // 0 default, else 1 + log2(proofs per workgroup) of that form
+    int witness_walk_log = 0;         // level form: 0 auto, 1 off, else 1 + log2(proofs per workgroup) of the one-launch tail
 };
 static Options g_default_options;
 static std::mutex g_options_mu;
@@ -243,6 +244,9 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_GRAPH: return tri(&o.graph);
         case RSV_OPT_WITNESS_LAYOUT: return tri(&o.witness_layout);
         case RSV_OPT_CAP_TOP: return tri(&o.cap_top);
+        case RSV_OPT_WITNESS_WALK_LOG:
+            if (value < 0 || value > 7) return RSV_E_RANGE;
+            o.witness_walk_log = (int)value; return RSV_OK;
         case RSV_OPT_WITNESS_SMALL_MAX:
             if (value < 0 || value > (1ll << 20) + 1) return RSV_E_RANGE;
             o.witness_small_max = value; return RSV_OK;

@@ -78,7 +78,7 @@ def test_options_are_explicit_and_validated(rsv):
         for v in (2, 1, 0):
             assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], v) == 0, name
     for name, bad, good in (("ws_budget_mb", 0, 8192), ("perm_wg_per_cu", 9, 8), ("host_chunk_mb", 0, 256), ("host_threads", 65, 0),
-                            ("debug_log", 2, 0), ("witness_small_max", (1 << 20) + 2, 0), ("witness_small_log", 8, 0)):
+                            ("debug_log", 2, 0), ("witness_small_max", (1 << 20) + 2, 0), ("witness_small_log", 8, 0), ("witness_walk_log", 8, 0)):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], bad) == -5, name
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], good) == 0, name
     # no getenv anywhere in the product sources, no RSV_ variable in the library's strings

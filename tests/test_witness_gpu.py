@@ -356,8 +356,9 @@ def test_witness_of_a_ragged_large_batch(rsv):
 
 
 def test_witness_launch_forms_agree(rsv):
-    """The level-per-launch form and the one-launch form (a workgroup per 1, 4, 64 proofs), forced through
-    RSV_OPT_WITNESS_SMALL_MAX / _LOG on batches of 3 and 70 proofs with a tampered one: the same rows as the gadgets'."""
+    """The level-per-launch form (its tail as a strip or in one launch) and the one-launch form (a workgroup per 1, 4, 64
+    proofs), forced through RSV_OPT_WITNESS_SMALL_MAX / _SMALL_LOG / _WALK_LOG on batches of 3 and 70 proofs with a tampered one:
+    the same rows as the gadgets'."""
     import torch
     name = "level12-1.bin"
     wp = rsv.WitnessProgram.build(read_proof(name), fixture_cfg(name), _inputs(name))
@@ -370,16 +371,20 @@ def test_witness_launch_forms_agree(rsv):
         blob, offsets = rsv.pack(batch)
         d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
         good = np.arange(n) != bad
-        for small_max, small_log in ((1, 0), (n + 1, 1), (n + 1, 3), (n + 1, 7), (0, 0)):
+        # (small_max, small_log, walk_log): level form with its tail as a strip / in one launch of 2, 8, 64 proofs per workgroup /
+        # by the default rule; the whole program in one launch of 1, 4, 64 proofs per workgroup; the default rule
+        for small_max, small_log, walk_log in ((1, 0, 1), (1, 0, 2), (1, 0, 4), (1, 0, 7), (1, 0, 0), (n + 1, 1, 0), (n + 1, 3, 0),
+                                               (n + 1, 7, 0), (0, 0, 0)):
             ctx.set_option("witness_small_max", small_max)
             ctx.set_option("witness_small_log", small_log)
+            ctx.set_option("witness_walk_log", walk_log)
             d_vars = torch.full((n, wp.n_vars, 4), -1, dtype=torch.int32, device=dev)
             d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
             ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(name))
             ctx.synchronize()
-            assert d_acc.cpu().numpy().tolist() == good.astype(int).tolist(), (n, small_max, small_log)
-            assert (d_vars.cpu().numpy().view(np.uint32)[good] == want[None]).all(), (n, small_max, small_log)
-    for opt, v in (("witness_small_max", (1 << 20) + 2), ("witness_small_log", 8), ("witness_small_max", -1)):
+            assert d_acc.cpu().numpy().tolist() == good.astype(int).tolist(), (n, small_max, small_log, walk_log)
+            assert (d_vars.cpu().numpy().view(np.uint32)[good] == want[None]).all(), (n, small_max, small_log, walk_log)
+    for opt, v in (("witness_small_max", (1 << 20) + 2), ("witness_small_log", 8), ("witness_small_max", -1), ("witness_walk_log", 8)):
         with pytest.raises(rsv.RsvError):
             ctx.set_option(opt, v)
     ctx.close()

@@ -53,6 +53,36 @@ def main():
             row.append(f" one launch, {1 << lg if n > 4 else 'n'} per workgroup: {ms:7.3f}{'' if ok else ' MISMATCH'}")
         print("".join(row), flush=True)
         del d_blob, d_vars, base
+    # the level form with its tail in one launch (RSV_OPT_WITNESS_WALK_LOG), mid-size batches
+    ctx.set_option("witness_small_max", 1)
+    for n in ([1024, 2048, 4096] if wp.n_vars > 200000 else [2048, 4096, 8192, 16384]):
+        blob, offsets = rsv.pack([proof] * n)
+        d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        d_vars = torch.zeros((n, wp.n_vars, 4), dtype=torch.int32, device=dev)
+        d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+        def run2(walk_log, steps=4):
+            ctx.set_option("witness_walk_log", walk_log)
+            d_vars.zero_()
+            ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=inputs)
+            ctx.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=inputs)
+            ctx.synchronize()
+            return (time.perf_counter() - t) / steps * 1e3
+
+        base_ms = run2(1)
+        base = d_vars.cpu()
+        row = [f"n {n:5d}  levels {base_ms:7.3f} ms |"]
+        ms = run2(0)
+        row.append(f" auto: {ms:7.3f}{'' if torch.equal(d_vars.cpu(), base) else ' MISMATCH'}")
+        for lg in (3, 4, 5):
+            ms = run2(lg + 1)
+            ok = bool(torch.equal(d_vars.cpu(), base))
+            row.append(f" tail in one launch, {1 << lg} per workgroup: {ms:7.3f}{'' if ok else ' MISMATCH'}")
+        print("".join(row), flush=True)
+        del d_blob, d_vars, base
     ctx.close()
     wp.close()
 
