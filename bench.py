@@ -469,7 +469,7 @@ def main():
             raise SystemExit("witness leg: a genuine proof was not accepted")
         witness = {"proofs_per_s": wn / wdt, "ms": wdt * 1e3, "proofs": wn, "fixture": wname, "variables_per_proof": wp.n_vars,
                    "levels": wp.n_levels, "output_GB": wn * wp.n_vars * 16 / 1e9, "program_build_s": wbuild,
-                   "includes": "the verifying pass with the hint outputs the program reads, the program (batches up to 1 024 proofs of a short program: one launch, a workgroup per four proofs; otherwise one launch per level, the narrow tail in one), the transpose "
+                   "includes": "the verifying pass with the hint outputs the program reads, the program (batches up to 1 024 proofs of a short program: one launch, a workgroup per four proofs; otherwise the wide head a launch per level and everything behind it in one), the transpose "
                                "(split and roofline: tools/bench_witness.py, profiles/r3_witness_*.json)"}
         wp.close()
         del d_wblob, d_wvars

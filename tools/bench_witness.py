@@ -109,7 +109,7 @@ def main():
                    "output_bytes_per_proof": 16 * prog.n_vars, "scratch_bytes": wp.scratch_bytes(n), "program_build_s": round(build_s, 2)},
         "split_ms": {"verifying_pass_with_hints": hints_ms, "levels_and_transpose": eval_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "note": f"the program ({len(prog.level_offsets) - 1} levels: one k_witness_small launch for batches up to 1 024 proofs of a short program, else k_witness_level[_wide] per level and the narrow tail in one k_witness_strip launch) + k_witness_transpose; algorithmic bytes/proof "
+                     "note": f"the program ({len(prog.level_offsets) - 1} levels: one k_witness_small launch for batches up to 1 024 proofs of a short program, else k_witness_level[_wide] for the wide head, a launch per level, and every level behind it in one k_witness_small launch) + k_witness_transpose; algorithmic bytes/proof "
                              f"{bytes_per_proof} = 16 B written per variable, 16 B per variable operand ({2 * n_two + n_one}), hint sources, "
                              "32 B per variable for the transpose"},
         "kernel_sources_sha": bench.kernel_sources_sha()}))
