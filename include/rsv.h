@@ -165,6 +165,8 @@ typedef enum rsv_option {
     RSV_OPT_WITNESS_SMALL_LOG = 18, /* 0 default, else 1 + log2(proofs per workgroup) of that form, 1 .. 7 */
     RSV_OPT_WITNESS_WALK_LOG = 20, /* rsv_witness_eval_dev, batches that run the program level by level: the levels behind the
                                      program's wide head in ONE launch, a workgroup per 2^k proofs: 0 auto, 1 off, else 1 + k (k = 1 .. 6) */
+    RSV_OPT_FLOW_CAP = 21,        /* passes that emit the PoseidonFlow: 0 / 1 a node several queries share is hashed once and the record
+                                     of every query through it written from there, 2 every lane hashes its whole path itself */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

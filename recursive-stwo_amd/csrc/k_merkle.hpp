@@ -115,16 +115,22 @@ struct CapGroup {
     const uint32_t* root;  // expected root (8 words)
     uint32_t* flags;       // ProofCtx::flags
     uint32_t hw_n, s_top, active, fail_bit;
+    uint4* frec;           // FLOW: this proof's PoseidonFlow records (nullptr: none)
+    uint8_t* fswap;
 };
 
 // emit (optional, path emission): this lane's path buffer; the sibling consumed at child level l + 1 goes to entry
 // emit_top - l (8 words each), so a query's path is complete although its lane does not walk the top levels.
-template <int BLOCK>
+// FLOW: a node several queries of a proof share is still ONE permutation here; the lane that hashes it writes the record
+// of every query whose path passes through it (the records differ only in which child is "self": swap = the position's
+// parity).  fl[0][lane] = record index of that query's step from level Lc (0xFFFFFFFF: none), fl[1][lane] = its position
+// at level Lc; the query lanes of group g are threads g * G .. g * G + G - 1.
+template <int BLOCK, bool FLOW = false>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
                                            const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0, uint32_t Lt = 0,
                                            uint32_t* capn = nullptr, uint32_t* capm = nullptr, uint32_t slot0 = 0, uint32_t n_slots = 0,
-                                           uint32_t T = 0, uint32_t ti = 0) {
+                                           uint32_t T = 0, uint32_t ti = 0, const uint32_t (*fl)[FLOW ? BLOCK : 1] = nullptr, uint32_t G = 0) {
     const uint32_t t = threadIdx.x;
     __syncthreads();  // xch is free, descriptors written
     if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
@@ -176,7 +182,22 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
                     left = (pres & 1u) ? load_hash(kids) : w8;
                     right = (pres & 2u) ? load_hash(kids + 8) : w8;
                 }
-                Hash8 node = hash_tree(left, right);
+                Hash8 node;
+                if constexpr (FLOW) {
+                    const State16 st = poseidon2(join(left, right));
+                    node = rate_of(st);
+                    if (d.frec) {
+                        const FlowSink fs{d.frec, d.fswap};
+                        for (uint32_t q = 0; q < G; q++) {
+                            const uint32_t idx0 = fl[0][g2 * G + q];
+                            if (idx0 == 0xFFFFFFFFu) continue;
+                            const uint32_t anc = fl[1][g2 * G + q] >> (Lc - 1u - l);  // the query's ancestor at the child level
+                            if ((anc >> 1) != ppos) continue;
+                            if (anc & 1u) flow_put(fs, idx0 + (Lc - 1u - l), right, left, st, 1u);
+                            else flow_put(fs, idx0 + (Lc - 1u - l), left, right, st, 0u);
+                        }
+                    }
+                } else node = hash_tree(left, right);
                 if (l == 0) {
                     if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, (1u << d.fail_bit) | (bad ? F_RESCAN : 0u));
                 } else {
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed;
+    __shared__ uint32_t capfl[2][FLOW ? BLOCK : 1];  // FLOW with a cap: see merkle_cap
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot_ = bx * per_block + grp;
@@ -270,6 +292,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
         if (live) {
             d.hw = hw; d.hw_n = hw_n; d.lvl = h->lvl; d.wf = nullptr; d.s_top = s_top;
             d.root = w + W_COMMIT0 + 8 * t; d.flags = &a.ctxs[p].flags; d.fail_bit = R_MERKLE_T0 + t;
+            d.frec = fs.rec; d.fswap = fs.swap;
         }
     }
     // Sibling exchange through LDS (and its workgroup barrier) only at the levels where some proof of this workgroup
@@ -359,8 +382,16 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
     }
     if (Lc) {
         uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
-        merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
-                          a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t);
+        if constexpr (FLOW) {
+            // this path's record of the step from level Lc: behind the leaf sponge, the steps above and — every column
+            // level lies above the cap — the lower column level's chunks + combine
+            const uint32_t lower = (live && t != 3 && A != B) ? umin(A, B) : 0u;
+            const uint32_t extra = lower ? flow_chunks(lower == A ? plonk_cols(t) : poseidon_cols(t)) + 1u : 0u;
+            capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + flow_chunks(nc_leaf) + 1u + (mx - Lc) + extra : 0xFFFFFFFFu;
+            capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
+        }
+        merkle_cap<BLOCK, FLOW>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
+                                a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t, capfl, G);
     }
 }
 
@@ -386,6 +417,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed[2];
+    __shared__ uint32_t capfl[2][FLOW ? BLOCK : 1];  // FLOW with a cap: see merkle_cap
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot_ = bx * per_block + grp;
@@ -448,6 +480,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
         if (live) {
             d.hw = w + L->hash_off; d.hw_n = L->hash_n; d.lvl = h->lvl; d.wf = slot == 0 ? h->wf : nullptr; d.s_top = s_top;
             d.root = w + L->commit_off; d.flags = &a.ctxs[p].flags; d.fail_bit = slot == 0 ? R_FRI_FIRST : R_FRI_INNER;
+            d.frec = fs.rec; d.fswap = fs.swap;
         }
     }
     // Workgroup barriers only where lanes really exchange through LDS (see k_trace_merkle): [0] child levels at which
@@ -550,8 +583,15 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
         const uint32_t fl = (ok ? 0u : 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER)) | ((bad || want_hw != L->hash_n) ? F_RESCAN : 0u);
         if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
-    if (Lc) merkle_cap<BLOCK>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
-                              a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot);
+    if (Lc) {
+        if constexpr (FLOW) {
+            // this path's record of the step from level Lc: every column level (four extra records each) lies above the cap
+            capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + 4u + (top - Lc) + 4u * dslot : 0xFFFFFFFFu;
+            capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
+        }
+        merkle_cap<BLOCK, FLOW>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
+                                a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot, capfl, G);
+    }
 }
 
 // ---------------------------------------------------------------- k_cap_top

@@ -1249,7 +1249,7 @@ def test_qconst_kernels_row_and_lane(rsv, manifest, knobs, mode):
 FLOW_SHAPES = ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level1-5.bin", "level9-1.bin", "level13-1.bin"]
 
 
-@pytest.mark.parametrize("form", ["row", "lane"])
+@pytest.mark.parametrize("form", ["row", "lane", "lane, every lane walks to the root"])
 @pytest.mark.parametrize("name", FLOW_SHAPES)
 def test_poseidon_flow_matches_oracle(rsv, manifest, knobs, name, form):
     """SURVEY 8f.1, second half: the PoseidonFlow records the verifying pass writes (rsv_hints_out::d_flow) == the
@@ -1258,7 +1258,10 @@ def test_poseidon_flow_matches_oracle(rsv, manifest, knobs, name, form):
     unequal column log sizes (level7-1: lp = lq, two column levels instead of three).  Every record is an invocation
     (perm(inputs) = outputs, checked on the GPU's own permutation entry point) and the count is the shape's.  Both forms of
     the transcript kernel write the channel's records: one proof per 16-lane row (small batches) and one proof per lane."""
-    knobs.set("transcript_form", form)
+    # default: the top-of-tree cap hashes a node several queries share ONCE and writes every query's record from there;
+    # flow_cap = off: every lane hashes (and records) its whole path itself
+    knobs.set("transcript_form", form.split(",")[0])
+    knobs.set("flow_cap", "off" if "," in form else "auto")
     entry = next(e for e in manifest if e["file"] == name)
     proof, inputs, cfg = read_proof(name), entry_inputs(entry), fixture_cfg(name)
     want = ob.poseidon_flow(proof, inputs)
