@@ -375,10 +375,10 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  *                                           (first layer, then inner layers; zero padded); [156..284) the raw query
  *                                           words in transcript order (zero padded).  Mixed shapes allowed.
  *   d_trace_sib / d_trace_pos               as rsv_trace_paths_dev   (both or neither)
- *   d_trace_cols [n][4][n_queries][64]      optional, with d_trace_sib: SinglePathMerkleProof::columns — the query's
+ *   d_trace_cols [n][4][n_queries][64]      optional (with or without d_trace_sib): SinglePathMerkleProof::columns — the query's
  *                                           column values at the leaf level, then those at the lower column log size
  *                                           (the packing rsv_merkle_path_root takes)
- *   d_fri_sib / d_fri_cols                  as rsv_fri_paths_dev     (both or neither)
+ *   d_fri_sib / d_fri_cols                  as rsv_fri_paths_dev     (both, or d_fri_cols alone)
  *   d_fri_folded [n][3][n_queries][4]       optional, with d_fri_sib: FirstLayerHints::folded_evals_by_column
  *                                           (components/hints/src/folding.rs:291-293) — the circle-to-line fold of
  *                                           each query's first-layer pair at the c-th column log size (descending)

@@ -462,15 +462,17 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
         }
         have_sib = true;
         dslot = 0;
-        if (a.pair_sib) {
+        if (a.pair_sib || a.pair_cols) {  // (the column values may be asked for without the sibling paths)
             const uint32_t oi = c->qperm[j];
             const size_t row = ((size_t)slot_ * (1 + a.maxInner) + slot) * G + oi;
-            psib = a.pair_sib + row * a.pl.maxM * 8;
-            uint32_t* pc = a.pair_cols + row * 3 * 8;
-            const uint32_t nlev = slot == 0 ? c->n_sizes : 1u;
-            for (uint32_t g = 0; g < nlev; g++) {
-                const uint32_t* src = leafv + ((size_t)(slot == 0 ? g : 2 + slot) * G + j) * 8;
-                for (int k = 0; k < 8; k++) pc[g * 8 + k] = src[k];
+            if (a.pair_sib) psib = a.pair_sib + row * a.pl.maxM * 8;
+            if (a.pair_cols) {
+                uint32_t* pc = a.pair_cols + row * 3 * 8;
+                const uint32_t nlev = slot == 0 ? c->n_sizes : 1u;
+                for (uint32_t g = 0; g < nlev; g++) {
+                    const uint32_t* src = leafv + ((size_t)(slot == 0 ? g : 2 + slot) * G + j) * 8;
+                    for (int k = 0; k < 8; k++) pc[g * 8 + k] = src[k];
+                }
             }
         }
     }

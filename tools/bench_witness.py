@@ -73,11 +73,8 @@ def main():
     ctx.set_option("witness_small_log", args.small_log)
     s = prog.shape
     M = max(s["lp"] + 1, s["lq"] + 2) + s["blowup"]
-    hint = dict(shape=(s["nq"], M, s["n_inner"]),
-                d_trace_sib=torch.empty((n, 4, s["nq"], M, 8), dtype=torch.int32, device=dev),
-                d_trace_pos=torch.empty((n, 4, s["nq"]), dtype=torch.int32, device=dev),
+    hint = dict(shape=(s["nq"], M, s["n_inner"]),  # what the witness call asks the verifying pass for: column values + the flow
                 d_trace_cols=torch.empty((n, 4, s["nq"], 64), dtype=torch.int32, device=dev),
-                d_fri_sib=torch.empty((n, 1 + s["n_inner"], s["nq"], M, 8), dtype=torch.int32, device=dev),
                 d_fri_cols=torch.empty((n, 1 + s["n_inner"], s["nq"], 3, 8), dtype=torch.int32, device=dev),
                 d_flow=torch.empty((n, s["flow_count"], 32), dtype=torch.int32, device=dev),
                 d_flow_swap=torch.empty((n, s["flow_count"]), dtype=torch.uint8, device=dev))
