@@ -203,6 +203,9 @@ def main():
                          "critical_chain=off.  The bench line is measured with none.")
     ap.add_argument("--witness-proofs", type=int, default=1024,
                     help="side leg: the recursion circuit's witness for this many proofs of the level10 shape (0 = skip; skipped with --perm-log2 0)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="one-GPU box only: every rank on cuda:0, bitmap exchange over gloo (RCCL refuses two ranks on one "
+                         "device).  The driver's runs never pass it: they use one GPU per rank and nccl (= RCCL).")
     ap.add_argument("--emit-flow", action="store_true",
                     help="also emit the PoseidonFlow of every proof's verification circuit (SURVEY 8f.1, second half: 128 B + "
                          "1 B per Poseidon invocation, ~0.7 MB per standard proof) from the verifying pass; any workload")
@@ -225,9 +228,9 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
-    # Rehearsal mode for a one-GPU box: RSV_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges the
-    # bitmaps over gloo (RCCL refuses two ranks on one device).  The driver's real runs use nccl (= RCCL).
-    rehearsal = os.environ.get("RSV_BENCH_REHEARSAL") == "1"
+    # Rehearsal mode for a one-GPU box (--rehearsal): every rank on cuda:0, the bitmaps exchanged over gloo (RCCL
+    # refuses two ranks on one device).  The driver's real runs use nccl (= RCCL).
+    rehearsal = args.rehearsal
     if torch.cuda.device_count() < (1 if rehearsal else world_env):
         raise SystemExit("bench.py needs one HIP device per rank: the product has no CPU fallback")
     for kv in args.knob:

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RSV_M31_P 0x7fffffffu
-#define RSV_ABI_VERSION 4
+#define RSV_ABI_VERSION 5
 
 typedef enum rsv_status {
     RSV_OK = 0,
@@ -44,7 +44,8 @@ typedef enum rsv_status {
     RSV_E_SIZE = -2,     /* inconsistent sizes / offsets not monotone / n too large */
     RSV_E_DEVICE = -3,   /* no such HIP device, or a HIP call failed */
     RSV_E_CAP = -4,      /* output capacity too small */
-    RSV_E_RANGE = -5     /* input word not a canonical M31 */
+    RSV_E_RANGE = -5,    /* input word not a canonical M31 */
+    RSV_E_UNAVAILABLE = -6 /* an optional run-time dependency (RCCL, for rsv_exchange_*) could not be loaded */
 } rsv_status;
 
 /* Why proof i was rejected.  Order = the order in which the reference's
@@ -526,9 +527,78 @@ int rsv_witness_eval(const rsv_witness_program* prog, const uint8_t* blob, const
 
 /* Pack n accept bytes (device) into a little-endian bitmap of ceil(n/32) u32
  * words (device) and return the popcount through *d_count (device u64, may be NULL).
- * This is the buffer the multi-GPU host exchanges with one RCCL all-gather. */
+ * This is the buffer the multi-GPU host exchanges with one RCCL all-gather (rsv_exchange_run, below). */
 int rsv_accept_bitmap_dev(rsv_ctx* ctx, const uint8_t* d_accept, size_t n,
                           uint32_t* d_bitmap, uint64_t* d_count);
+
+/* ---- e: more than one GPU (BASELINE configs[3]) -----------------------------------------------------------
+ * Proofs are independent, so a job shards by contiguous index range and NOTHING is exchanged while it verifies; what is
+ * left is to put the shards' accept bits together.  Two layouts, both behind this header:
+ *
+ * (1) ONE process drives N devices — what the reference's driver is (examples/multi-proofs/src/main.rs:198-295: one
+ *     process walks the whole chain).  rsv_multi holds one context per entry of `devices` (a device may be named more
+ *     than once: several contexts on one GPU) and runs one host thread per context per call.  A process that owns every
+ *     shard has nobody to send to, so the job's accept bytes / bitmap / count are assembled on the host: no collective.
+ * (2) One process per GPU (torchrun, MPI, N copies of a Rust binary).  Each rank verifies its shard and the ranks
+ *     exchange their bitmap slices with ONE ncclAllGather and their counts with ONE ncclAllReduce over RCCL / xGMI
+ *     (rsv_exchange).  RCCL is bound at run time, never linked; RSV_E_UNAVAILABLE where it cannot be loaded.
+ *
+ * Shard rule (both layouts, and recursive-stwo_amd/sharding.py): rank r of `world` owns [lo, hi) with sizes differing
+ * by at most one, the larger shards first. */
+void rsv_shard_range(size_t n_total, size_t rank, size_t world, size_t* lo, size_t* hi);
+
+typedef struct rsv_multi rsv_multi;
+/* n_devices in 1 .. 64; every entry a valid HIP device index (RSV_E_DEVICE otherwise). */
+int rsv_multi_create(const int* devices, size_t n_devices, rsv_multi** out);
+void rsv_multi_destroy(rsv_multi* m);
+size_t rsv_multi_size(const rsv_multi* m);
+/* Context of rank r (owned by m): for rsv_ctx_set_option, or to use a rank on its own.  NULL if out of range. */
+rsv_ctx* rsv_multi_ctx(rsv_multi* m, size_t rank);
+/* The whole job in HOST memory, as the reference's caller holds it (one serialized buffer per proof): rank r runs
+ * rsv_verify_batch_host on shard rsv_shard_range(n, r, size) from its own thread (gather -> pinned -> DMA -> verify,
+ * pipelined per device).  accept / reason: n bytes each (reason may be NULL); bitmap: ceil(n / 32) little-endian words
+ * (bit i = accept[i]) or NULL; count: accepted proofs or NULL.  cfg->cfg_of (HOST memory here) indexes the whole job.
+ * Blocks until every verdict is written.  The first failing rank's status is returned. */
+int rsv_multi_verify_batch_host(rsv_multi* m, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
+                                const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
+                                uint8_t* reason, uint32_t* bitmap, uint64_t* count);
+/* The job already resident in HBM, shard r on the device of context r (the caller chose the split; the job's proof
+ * order is shard 0, shard 1, ...).  Pointers are DEVICE pointers of that device, as for rsv_verify_batch_dev;
+ * d_cfg_of / d_accept / d_reason may be NULL (no per-proof configuration index / verdict bytes not wanted). */
+typedef struct rsv_shard {
+    const uint8_t* d_blob;
+    const uint64_t* d_offsets;
+    size_t n;
+    const uint8_t* d_cfg_of;
+    uint8_t* d_accept;
+    uint8_t* d_reason;
+} rsv_shard;
+/* n_shards must equal rsv_multi_size(m).  Every context verifies its shard (one pass that also packs the shard's
+ * bitmap and count, rsv_hints_out::d_accept_bitmap), the slices come back over PCIe (n / 8 bytes) and are placed at
+ * their bit offsets: bitmap = ceil(sum n / 32) HOST words or NULL, count = HOST u64 or NULL.  cfg->cfg_of is ignored
+ * (each shard has its own d_cfg_of).  Blocks until all contexts are done. */
+int rsv_multi_verify_batch_dev(rsv_multi* m, const rsv_shard* shards, size_t n_shards, const rsv_cfg_set* cfg,
+                               const rsv_public_input* pi, size_t n_pi, uint32_t* bitmap, uint64_t* count);
+
+/* Layout (2).  rank 0 obtains an id (ncclGetUniqueId) and hands its RSV_EXCHANGE_ID_BYTES bytes to the other ranks by
+ * whatever channel the host has (a file, an environment variable, MPI, a torch store); every rank then calls
+ * rsv_exchange_create — collectively: it returns when all `world` ranks have joined (ncclCommInitRank on ctx's device).
+ * Per batch: verify the shard with rsv_verify_hints_dev asking for d_accept_bitmap = d_local (slice_words words, the
+ * library zeroes the bits above the shard) and d_accept_count = d_count, then rsv_exchange_run — enqueued on ctx's
+ * stream behind the verifying pass, no host synchronisation: afterwards d_gathered [world][slice_words] holds every
+ * rank's slice and *d_count the job's total on every rank.  rsv_exchange_assemble (pure host arithmetic, no RCCL
+ * needed) turns a host copy of d_gathered into the job's accept bytes and / or contiguous bitmap. */
+#define RSV_EXCHANGE_ID_BYTES 128
+typedef struct rsv_exchange rsv_exchange;
+int rsv_exchange_available(void);     /* 1 if RCCL could be bound in this process, else 0 */
+int rsv_exchange_rccl_version(void);  /* ncclGetVersion, 0 if unavailable */
+int rsv_exchange_unique_id(uint8_t* id128);
+int rsv_exchange_create(rsv_ctx* ctx, const uint8_t* id128, int rank, int world, size_t n_total, rsv_exchange** out);
+void rsv_exchange_destroy(rsv_exchange* x);
+/* This rank's [lo, hi) and the slice size every rank contributes (the largest shard's bitmap words, at least 1). */
+int rsv_exchange_layout(const rsv_exchange* x, size_t* lo, size_t* hi, size_t* slice_words);
+int rsv_exchange_run(rsv_exchange* x, const uint32_t* d_local, uint32_t* d_gathered, uint64_t* d_count);
+int rsv_exchange_assemble(size_t n_total, size_t world, const uint32_t* gathered, uint8_t* accept, uint32_t* bitmap);
 
 /* Per-stage kernel time of the last rsv_verify_batch_dev on this ctx, measured
  * with HIP events on the ctx stream (ms).  names[i] are static strings.

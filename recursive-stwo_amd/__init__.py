@@ -26,7 +26,8 @@ import numpy as np
 
 P = 0x7FFFFFFF
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RSV_LIB") or os.path.join(_HERE, "csrc", "librsv_hip.so")  # RSV_LIB: diagnostic builds (tools/)
+# (rsvload.load_package(lib_path=...) names a diagnostic build explicitly; nothing here reads the environment)
+LIB_PATH = globals().get("_LIB_PATH_OVERRIDE") or os.path.join(_HERE, "csrc", "librsv_hip.so")
 
 REASONS = ["ok", "parse", "pow", "logup", "composition", "dup_query", "merkle_t0", "merkle_t1",
            "merkle_t2", "merkle_t3", "fri_first", "fri_inner", "fri_last"]
@@ -38,7 +39,7 @@ _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 class RsvError(RuntimeError):
     def __init__(self, code: int, what: str):
-        names = {-1: "RSV_E_NULL", -2: "RSV_E_SIZE", -3: "RSV_E_DEVICE", -4: "RSV_E_CAP", -5: "RSV_E_RANGE"}
+        names = {-1: "RSV_E_NULL", -2: "RSV_E_SIZE", -3: "RSV_E_DEVICE", -4: "RSV_E_CAP", -5: "RSV_E_RANGE", -6: "RSV_E_UNAVAILABLE"}
         super().__init__(f"{what}: {names.get(code, code)}")
         self.code = code
 
@@ -128,7 +129,13 @@ class WitnessShape(ctypes.Structure):  # rsv_witness_shape
                                                "n_inner", "flow_count", "copies")]
 
 
+class Shard(ctypes.Structure):  # rsv_shard
+    _fields_ = [("d_blob", ctypes.c_void_p), ("d_offsets", ctypes.c_void_p), ("n", ctypes.c_size_t), ("d_cfg_of", ctypes.c_void_p),
+                ("d_accept", ctypes.c_void_p), ("d_reason", ctypes.c_void_p)]
+
+
 TRANSCRIPT_WORDS = 284  # RSV_TRANSCRIPT_WORDS
+EXCHANGE_ID_BYTES = 128  # RSV_EXCHANGE_ID_BYTES
 
 
 def _load() -> ctypes.CDLL:
@@ -202,6 +209,23 @@ def _load() -> ctypes.CDLL:
         "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp, vp, vp]),
         "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u32p, _u8p,
                                             _u8p, _u8p, ctypes.c_int]),
+        "rsv_shard_range": (None, [sz, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "rsv_multi_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), sz, ctypes.POINTER(vp)]),
+        "rsv_multi_destroy": (None, [vp]),
+        "rsv_multi_size": (sz, [vp]),
+        "rsv_multi_ctx": (vp, [vp, sz]),
+        "rsv_multi_verify_batch_host": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_void_p), _u64p, sz, ctypes.POINTER(CfgSet),
+                                                       ctypes.POINTER(PublicInput), sz, _u8p, _u8p, _u32p, _u64p]),
+        "rsv_multi_verify_batch_dev": (ctypes.c_int, [vp, ctypes.POINTER(Shard), sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz,
+                                                      _u32p, _u64p]),
+        "rsv_exchange_available": (ctypes.c_int, []),
+        "rsv_exchange_rccl_version": (ctypes.c_int, []),
+        "rsv_exchange_unique_id": (ctypes.c_int, [_u8p]),
+        "rsv_exchange_create": (ctypes.c_int, [vp, _u8p, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(vp)]),
+        "rsv_exchange_destroy": (None, [vp]),
+        "rsv_exchange_layout": (ctypes.c_int, [vp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "rsv_exchange_run": (ctypes.c_int, [vp, vp, vp, vp]),
+        "rsv_exchange_assemble": (ctypes.c_int, [sz, sz, _u32p, _u8p, _u32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what rsv.h declares
@@ -220,7 +244,10 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_line_eval", "rsv_oods_eval", "rsv_last_layer_check",
            "rsv_transcript_batch", "rsv_poseidon_flow_count", "rsv_witness_program_create", "rsv_witness_program_destroy",
            "rsv_witness_program_build", "rsv_witness_program_info", "rsv_witness_program_export", "rsv_witness_program_gates",
-           "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval"]
+           "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval",
+           "rsv_shard_range", "rsv_multi_create", "rsv_multi_destroy", "rsv_multi_size", "rsv_multi_ctx", "rsv_multi_verify_batch_host",
+           "rsv_multi_verify_batch_dev", "rsv_exchange_available", "rsv_exchange_rccl_version", "rsv_exchange_unique_id",
+           "rsv_exchange_create", "rsv_exchange_destroy", "rsv_exchange_layout", "rsv_exchange_run", "rsv_exchange_assemble"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -827,6 +854,124 @@ class Context:
         if k < 0:
             raise RsvError(k, "rsv_last_stage_times")
         return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """rsv_shard_range: the contiguous [lo, hi) of rank `rank` (the rule sharding.shard_range restates in Python)."""
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    lib.rsv_shard_range(n_total, rank, world, ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+class MultiContext:
+    """rsv_multi: ONE process drives several contexts (one per entry of `devices`; a device may repeat), one host thread
+    per context per call; the job's verdicts, bitmap and count are assembled on the host (no collective)."""
+
+    def __init__(self, devices: Sequence[int]):
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        _check(lib.rsv_multi_create(arr, len(devices), ctypes.byref(h)), "rsv_multi_create")
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if self._h:
+            lib.rsv_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib.rsv_multi_size(self._h))
+
+    def set_option(self, name: str, value) -> None:
+        for r in range(len(self)):
+            _set_option(ctypes.c_void_p(lib.rsv_multi_ctx(self._h, r)), name, value)
+
+    def verify_batch_host(self, proofs, cfg, inputs=STANDARD_INPUTS):
+        """The whole job in host memory (bytes / numpy buffers or a HostBatch).  Returns (accept, reason, bitmap, count)."""
+        hb = proofs if isinstance(proofs, HostBatch) else HostBatch(proofs)
+        n = hb.n
+        accept, reason = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        bitmap = np.zeros(max(1, (n + 31) // 32), np.uint32)
+        count = ctypes.c_uint64()
+        pi = make_inputs(inputs)
+        pc = prepare_cfg(cfg, n)
+        _check(lib.rsv_multi_verify_batch_host(self._h, hb.ptrs, hb.lens.ctypes.data_as(_u64p), n, pc.ref(), pi, len(list(inputs)),
+                                               accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), bitmap.ctypes.data_as(_u32p),
+                                               ctypes.byref(count)), "rsv_multi_verify_batch_host")
+        return accept, reason, bitmap[: (n + 31) // 32], int(count.value)
+
+    def verify_batch_dev(self, shards, cfg_table: Sequence[PcsConfig], inputs=STANDARD_INPUTS):
+        """shards: one dict per context with torch tensors on that context's device: d_blob, d_offsets, n, and optionally
+        d_cfg_of / d_accept / d_reason.  The caller has synchronised whatever produced them (the call waits for nothing
+        of torch's).  Returns (bitmap uint32[ceil(sum n / 32)], count)."""
+        if len(shards) != len(self):
+            raise ValueError("one shard per context")
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        arr = (Shard * len(shards))(*[Shard(ptr(s["d_blob"]), ptr(s["d_offsets"]), int(s["n"]), ptr(s.get("d_cfg_of")),
+                                            ptr(s.get("d_accept")), ptr(s.get("d_reason"))) for s in shards])
+        n_total = sum(int(s["n"]) for s in shards)
+        bitmap = np.zeros(max(1, (n_total + 31) // 32), np.uint32)
+        count = ctypes.c_uint64()
+        pi = make_inputs(inputs)
+        pc = PreparedCfg(list(cfg_table))
+        _check(lib.rsv_multi_verify_batch_dev(self._h, arr, len(shards), pc.ref(), pi, len(list(inputs)), bitmap.ctypes.data_as(_u32p),
+                                              ctypes.byref(count)), "rsv_multi_verify_batch_dev")
+        return bitmap[: (n_total + 31) // 32], int(count.value)
+
+
+def exchange_available() -> bool:
+    return bool(lib.rsv_exchange_available())
+
+
+def exchange_unique_id() -> bytes:
+    buf = (ctypes.c_uint8 * EXCHANGE_ID_BYTES)()
+    _check(lib.rsv_exchange_unique_id(buf), "rsv_exchange_unique_id")
+    return bytes(buf)
+
+
+def exchange_assemble(n_total: int, world: int, gathered: np.ndarray):
+    """rsv_exchange_assemble: gathered [world][slice_words] (host) -> (accept bytes, contiguous bitmap) of the job."""
+    g = np.ascontiguousarray(gathered, dtype=np.uint32)
+    accept = np.zeros(max(n_total, 1), np.uint8)
+    bitmap = np.zeros(max(1, (n_total + 31) // 32), np.uint32)
+    _check(lib.rsv_exchange_assemble(n_total, world, g.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), bitmap.ctypes.data_as(_u32p)),
+           "rsv_exchange_assemble")
+    return accept[:n_total], bitmap[: (n_total + 31) // 32]
+
+
+class Exchange:
+    """rsv_exchange: the one-process-per-GPU collective step over RCCL, driven through the C-ABI (no torch.distributed on
+    the data path).  `uid` = exchange_unique_id() of rank 0, distributed by the caller.  Collective constructor."""
+
+    def __init__(self, ctx: "Context", uid: bytes, rank: int, world: int, n_total: int):
+        buf = (ctypes.c_uint8 * EXCHANGE_ID_BYTES).from_buffer_copy(uid)
+        h = ctypes.c_void_p()
+        _check(lib.rsv_exchange_create(ctx._h, buf, rank, world, n_total, ctypes.byref(h)), "rsv_exchange_create")
+        self._h, self.ctx, self.rank, self.world, self.n_total = h, ctx, rank, world, n_total
+        lo, hi, sw = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _check(lib.rsv_exchange_layout(h, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(sw)), "rsv_exchange_layout")
+        self.lo, self.hi, self.slice_words = lo.value, hi.value, sw.value
+
+    def run(self, d_local, d_gathered, d_count=None):
+        _check(lib.rsv_exchange_run(self._h, d_local.data_ptr(), d_gathered.data_ptr(), d_count.data_ptr() if d_count is not None else None),
+               "rsv_exchange_run")
+
+    def close(self):
+        if self._h:
+            lib.rsv_exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 from . import witness_program  # noqa: E402,F401  (the witness program container)

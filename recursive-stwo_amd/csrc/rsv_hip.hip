@@ -480,6 +480,7 @@ int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint
 
 #include "verify_api.inc"
 #include "host_stream.inc"
+#include "multi_api.inc"
 #include "witness_api.inc"
 #include "circuit_verifier.hpp"
 #include "circuit_builder.inc"

@@ -668,36 +668,68 @@ struct Verifier {
     // whose header carries another configuration is rejected (RSV_R_PARSE), as the reference never reads it from there.
     static void verify_batch(const std::vector<std::vector<uint8_t>>& proofs, const std::vector<PcsConfig>& configs,
                              const Inputs& inputs, std::vector<uint8_t>& accept, std::vector<uint8_t>& reason) {
-        if (configs.empty() || (configs.size() != 1 && configs.size() != proofs.size()))
-            throw DeviceError("verify_batch: one PcsConfig, or one per proof", RSV_E_SIZE);
-        // distinct configurations + per-proof index (rsv_cfg_set)
-        std::vector<rsv_pcs_config> table;
-        std::vector<uint8_t> cfg_of(configs.size() == 1 ? 0 : proofs.size());
-        for (size_t i = 0; i < configs.size(); i++) {
-            const rsv_pcs_config c = configs[i].abi();
-            size_t k = 0;
-            while (k < table.size() && !(table[k].pow_bits == c.pow_bits && table[k].log_blowup_factor == c.log_blowup_factor &&
-                                         table[k].log_last_layer_degree_bound == c.log_last_layer_degree_bound &&
-                                         table[k].n_queries == c.n_queries))
-                k++;
-            if (k == table.size()) {
-                if (table.size() == RSV_MAX_CFGS) throw DeviceError("verify_batch: too many distinct configurations", RSV_E_SIZE);
-                table.push_back(c);
-            }
-            if (!cfg_of.empty()) cfg_of[i] = (uint8_t)k;
-        }
-        const rsv_cfg_set cfg_set{table.data(), (uint32_t)table.size(), cfg_of.empty() ? nullptr : cfg_of.data()};
-        // one buffer per proof, as the reference holds them: the library gathers, uploads and verifies in a pipeline
-        std::vector<const uint8_t*> ptrs;
-        std::vector<uint64_t> lens;
-        for (auto& p : proofs) { ptrs.push_back(p.data()); lens.push_back(p.size()); }
+        Job job(proofs, configs);
         accept.assign(proofs.size(), 0);
         reason.assign(proofs.size(), 0);
         auto pi = abi_inputs(inputs);
-        check(rsv_verify_batch_host(thread_context(), ptrs.data(), lens.data(), proofs.size(), &cfg_set, pi.data(),
+        check(rsv_verify_batch_host(thread_context(), job.ptrs.data(), job.lens.data(), proofs.size(), &job.cfg_set, pi.data(),
                                     pi.size(), accept.data(), reason.data()),
               "rsv_verify_batch_host");
     }
+    // The same job over several devices from this ONE process — the reference's driver is one process that walks the whole
+    // chain (examples/multi-proofs/src/main.rs:198-295): contiguous shards (rsv_shard_range), one host thread per device,
+    // verdicts + accept bitmap + count assembled on the host (rsv_multi_verify_batch_host; nothing is exchanged between
+    // the devices).  `devices` may name a device more than once.  Returns the number of accepted proofs.
+    static uint64_t verify_batch_multi(const std::vector<int>& devices, const std::vector<std::vector<uint8_t>>& proofs,
+                                       const std::vector<PcsConfig>& configs, const Inputs& inputs, std::vector<uint8_t>& accept,
+                                       std::vector<uint8_t>& reason, std::vector<uint32_t>* bitmap = nullptr) {
+        Job job(proofs, configs);
+        accept.assign(proofs.size(), 0);
+        reason.assign(proofs.size(), 0);
+        if (bitmap) bitmap->assign((proofs.size() + 31) / 32, 0u);
+        auto pi = abi_inputs(inputs);
+        rsv_multi* m = nullptr;
+        check(rsv_multi_create(devices.data(), devices.size(), &m), "rsv_multi_create");
+        uint64_t count = 0;
+        const int st = rsv_multi_verify_batch_host(m, job.ptrs.data(), job.lens.data(), proofs.size(), &job.cfg_set, pi.data(), pi.size(),
+                                                   accept.data(), reason.data(), bitmap ? bitmap->data() : nullptr, &count);
+        rsv_multi_destroy(m);
+        check(st, "rsv_multi_verify_batch_host");
+        return count;
+    }
+
+   private:
+    // one buffer per proof, as the reference holds them (the library gathers, uploads and verifies in a pipeline), and the
+    // distinct configurations + per-proof index (rsv_cfg_set)
+    struct Job {
+        std::vector<rsv_pcs_config> table;
+        std::vector<uint8_t> cfg_of;
+        std::vector<const uint8_t*> ptrs;
+        std::vector<uint64_t> lens;
+        rsv_cfg_set cfg_set{};
+        Job(const std::vector<std::vector<uint8_t>>& proofs, const std::vector<PcsConfig>& configs) {
+            if (configs.empty() || (configs.size() != 1 && configs.size() != proofs.size()))
+                throw DeviceError("verify_batch: one PcsConfig, or one per proof", RSV_E_SIZE);
+            cfg_of.resize(configs.size() == 1 ? 0 : proofs.size());
+            for (size_t i = 0; i < configs.size(); i++) {
+                const rsv_pcs_config c = configs[i].abi();
+                size_t k = 0;
+                while (k < table.size() && !(table[k].pow_bits == c.pow_bits && table[k].log_blowup_factor == c.log_blowup_factor &&
+                                             table[k].log_last_layer_degree_bound == c.log_last_layer_degree_bound &&
+                                             table[k].n_queries == c.n_queries))
+                    k++;
+                if (k == table.size()) {
+                    if (table.size() == RSV_MAX_CFGS) throw DeviceError("verify_batch: too many distinct configurations", RSV_E_SIZE);
+                    table.push_back(c);
+                }
+                if (!cfg_of.empty()) cfg_of[i] = (uint8_t)k;
+            }
+            cfg_set = rsv_cfg_set{table.data(), (uint32_t)table.size(), cfg_of.empty() ? nullptr : cfg_of.data()};
+            for (auto& p : proofs) { ptrs.push_back(p.data()); lens.push_back(p.size()); }
+        }
+    };
+
+   public:
     // Reference behaviour for one proof: returns on success, "panics" (throws) at the failing stage.
     static void verify(const std::vector<uint8_t>& proof, const PcsConfig& config, const Inputs& inputs) {
         std::vector<uint8_t> a, r;

@@ -173,16 +173,17 @@ def launch_ranks(script: str, argv, n_ranks: int, env=None) -> int:
     return subprocess.call(cmd, env=e)
 
 
-def init_rank(torch, dist, rehearsal: bool = False):
-    """Per-rank setup from the torchrun environment: (rank, world, device_index).  Backend "nccl" (= RCCL) with the
-    rank's own GPU; in rehearsal mode (a one-GPU box) every rank uses cuda:0 and the exchange runs over gloo, since
-    RCCL refuses two ranks on one device."""
+def init_rank(torch, dist, rehearsal: bool = False, force_group: bool = False):
+    """Per-rank setup from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, the launcher's
+    contract): (rank, world, device_index).  Backend "nccl" (= RCCL) with the rank's own GPU; in rehearsal mode (a
+    one-GPU box) every rank uses cuda:0 and the exchange runs over gloo, since RCCL refuses two ranks on one device.
+    force_group: a process group even at world size 1 (the tests drive the real RCCL backend that way)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1 or os.environ.get("RSV_FORCE_PROCESS_GROUP") == "1":
+    if world > 1 or force_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if rehearsal:

@@ -8,11 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RSV_LIB"] = os.path.join(ROOT, "recursive-stwo_amd", "csrc", "librsv_hip_count.so")
 import rsvload  # noqa: E402
 from tests import oracle_binding as ob  # noqa: E402
 
-rsv = rsvload.load_package()
+rsv = rsvload.load_package(lib_path=os.path.join(ROOT, "recursive-stwo_amd", "csrc", "librsv_hip_count.so"))
 
 
 TAGS = {0: "other", 1: "k_transcript", 2: "k_row_hash", 3: "k_trace_merkle", 4: "k_pair_merkle"}

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rsv):
     lib = ctypes.CDLL(rsv.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rsv.h but not exported by librsv_hip.so"
-    assert lib.rsv_abi_version() == 4
+    assert lib.rsv_abi_version() == 5
     assert sorted(rsv.EXPORTS) == declared_functions()
 
 
@@ -99,3 +99,23 @@ def test_poseidon_flow_count_is_host_arithmetic(rsv):
     assert rsv.poseidon_flow_count(19, 18, fixture_cfg("level1-5.bin")) == 28095
     with pytest.raises(rsv.RsvError):
         rsv.poseidon_flow_count(0, 8, fixture_cfg("small_proof.bin"))
+
+
+def test_rust_mirror_matches_header():
+    """INTEGRATION.md §1 (the Rust `extern "C"` block of the rsv-sys crate) is generated from include/rsv.h by
+    tools/gen_rust_ffi.py; no Rust compiler exists in the image, so this diff is what keeps the mirror from drifting:
+    every declared function appears exactly once with the header's argument list, every struct field and constant too."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.function_names() == declared_functions()          # the generator's parser sees what this file's regex sees
+    want, have = gen.generate(), gen.committed_block()
+    assert have == want, "INTEGRATION.md §1 differs from include/rsv.h: run `python tools/gen_rust_ffi.py --write`"
+    for name in declared_functions():
+        assert have.count(f"pub fn {name}(") == 1, name
+    # spot checks of the type mapping
+    assert "pub fn rsv_verify_batch_host(ctx: *mut rsv_ctx, proofs: *const *const u8, lens: *const u64, n: usize," in have
+    assert "pub fn rsv_last_stage_times(ctx: *mut rsv_ctx, names: *mut *const c_char, ms: *mut f32, cap: c_int) -> c_int;" in have
+    assert "pub struct rsv_public_input { pub idx: u32, pub value: [u32; 4] }" in have
+    assert "pub fn rsv_ctx_set_option(ctx: *mut rsv_ctx, option: c_int, value: i64) -> c_int;" in have

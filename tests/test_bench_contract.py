@@ -1,5 +1,5 @@
 """bench.py contract: one JSON line with the fields the driver reads; the N>1 path is rehearsed with two
-ranks on one GPU (RSV_BENCH_REHEARSAL=1: bitmap exchange over gloo, since RCCL refuses two ranks per device), here in
+ranks on one GPU (`--rehearsal`: bitmap exchange over gloo, since RCCL refuses two ranks per device), here in
 the explicit torchrun form the driver uses for N > 1 (tests/test_multi_gpu.py covers the self-launching form)."""
 import json
 import os
@@ -68,9 +68,9 @@ def test_bench_single_gpu_line():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal():
-    env = dict(os.environ, RSV_BENCH_REHEARSAL="1")
+    env = dict(os.environ)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--proofs", "2048",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--proofs", "2048",
            "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]

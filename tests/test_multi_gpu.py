@@ -26,9 +26,8 @@ import torch, torch.distributed as dist
 from tests import oracle_binding as ob
 from tests.conftest import read_proof, fixture_cfg
 
-os.environ["RSV_FORCE_PROCESS_GROUP"] = "1"          # world_size 1 still goes through RCCL
 os.environ.setdefault("MASTER_PORT", str(sharding.free_port()))
-rank, world, dev_index = sharding.init_rank(torch, dist)
+rank, world, dev_index = sharding.init_rank(torch, dist, force_group=True)   # world_size 1 still goes through RCCL
 assert dist.get_backend() == "nccl" and world == 1
 dev = torch.device("cuda", dev_index)
 proof = read_proof("recursive_proof_16_15.bin")
@@ -80,8 +79,7 @@ def _bench(args, env_extra):
 
 def test_bench_launches_its_own_ranks():
     """The driver's shape: `python3 bench.py --gpus 2 --steps K --warmup W` as ONE plain process."""
-    d = _bench(["--gpus", "2", "--proofs", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"],
-               {"RSV_BENCH_REHEARSAL": "1"})
+    d = _bench(["--gpus", "2", "--rehearsal", "--proofs", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "shard2"
     ex = d["config"]["exchange"]
     assert d["config"]["proofs_per_step"] == 4096 and d["value"] > 0 and "gloo" in ex["collectives"]
@@ -91,9 +89,188 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_bench_total_proofs_strong_scaling():
-    d = _bench(["--gpus", "2", "--total-proofs", "4099", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"],
-               {"RSV_BENCH_REHEARSAL": "1"})
+    d = _bench(["--gpus", "2", "--rehearsal", "--total-proofs", "4099", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 4099
     assert d["config"]["proofs_rank0"] == 2050
     d1 = _bench(["--total-proofs", "3000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
     assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["proofs_rank0"] == 3000
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Multi-GPU BEHIND the C-ABI (include/rsv.h, section e): one process, several contexts.  Three contexts on cuda:0 stand
+# in for three GPUs; the shards are unequal; verdicts and reasons must be the oracle's, the bitmap ShardedVerifier's.
+def _mixed_job(ob, n):
+    from tests.conftest import fixture_cfg, read_proof
+    names = ["recursive_proof_16_15.bin", "level1-5.bin", "level12-1.bin", "small_proof.bin", "level3-1.bin"]
+    proofs, cfgs = [], []
+    for i in range(n):
+        name = names[i % len(names)]
+        p = read_proof(name)
+        if i % 7 == 3:
+            p = ob.tamper(p, i)
+        if i % 41 == 17:
+            p = p[: len(p) // 2]          # truncated
+        if i % 53 == 29:
+            p = b""                       # empty buffer
+        proofs.append(p)
+        cfgs.append(fixture_cfg(name))
+    return proofs, cfgs
+
+
+def test_multi_host_three_contexts_unequal_shards(rsv):
+    """rsv_multi_verify_batch_host with devices = {0, 0, 0}: 1 000 proofs of five shapes / four configurations (shards
+    334 / 333 / 333), tampered, truncated and empty buffers among them."""
+    import numpy as np
+    from recursive_stwo_amd import sharding
+    from tests import oracle_binding as ob
+    n = 1000
+    proofs, cfgs = _mixed_job(ob, n)
+    mc = rsv.MultiContext([0, 0, 0])
+    assert len(mc) == 3 and [rsv.shard_range(n, r, 3) for r in range(3)] == [sharding.shard_range(n, r, 3) for r in range(3)]
+    acc, reason, bitmap, count = mc.verify_batch_host(proofs, cfgs)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
+    assert np.array_equal(acc, oacc) and np.array_equal(reason, oreason)
+    assert 0 < int(acc.sum()) < n and count == int(acc.sum())
+    assert np.array_equal(bitmap, sharding.pack_bitmap(acc))
+    # again on the same object (rings and workspaces reused), one configuration for the whole job, fewer proofs than contexts
+    one = [p for p, c in zip(proofs, cfgs) if c.n_queries == 16][:2]
+    acc2, reason2, bitmap2, count2 = mc.verify_batch_host(one, fixture_cfg_std())
+    o2, r2 = ob.verify_batch(one, fixture_cfg_std())
+    assert np.array_equal(acc2, o2) and np.array_equal(reason2, r2) and count2 == int(o2.sum()) and bitmap2.tolist() == [int(sharding.pack_bitmap(o2)[0])]
+    mc.close()
+
+
+def fixture_cfg_std():
+    from tests.conftest import fixture_cfg
+    return fixture_cfg("recursive_proof_16_15.bin")
+
+
+def test_multi_dev_shards_bitmap_equals_sharded_verifier(rsv):
+    """rsv_multi_verify_batch_dev: the job resident in HBM as three shards the CALLER cut (37 / 0 / 563 proofs, not word
+    aligned), per-shard configuration index; the host-assembled bitmap == the slices ShardedVerifier (the Python
+    exchange) produces for the same job, == the oracle's accept vector."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from recursive_stwo_amd import sharding
+    from tests import oracle_binding as ob
+    n = 600
+    proofs, cfgs = _mixed_job(ob, n)
+    table, index, of = [], {}, np.zeros(n, np.uint8)
+    for i, c in enumerate(cfgs):
+        k = rsv._cfg_key(c)
+        if k not in index:
+            index[k] = len(table)
+            table.append(c)
+        of[i] = index[k]
+    dev = torch.device("cuda:0")
+    cuts = [0, 37, 37, n]
+    shards, keep = [], []
+    for r in range(3):
+        lo, hi = cuts[r], cuts[r + 1]
+        if hi == lo:
+            shards.append({"d_blob": None, "d_offsets": None, "n": 0})
+            continue
+        blob, offsets = rsv.pack(proofs[lo:hi])
+        t = {"d_blob": torch.from_numpy(blob.copy()).to(dev), "d_offsets": torch.from_numpy(offsets.astype(np.int64)).to(dev), "n": hi - lo,
+             "d_cfg_of": torch.from_numpy(of[lo:hi].copy()).to(dev), "d_accept": torch.full((hi - lo,), 7, dtype=torch.uint8, device=dev),
+             "d_reason": torch.full((hi - lo,), 77, dtype=torch.uint8, device=dev)}
+        if r == 2:
+            t["d_accept"] = None          # verdict bytes not wanted for this shard: the bitmap still carries them
+        shards.append(t)
+        keep.append(t)
+    torch.cuda.synchronize()
+    mc = rsv.MultiContext([0, 0, 0])
+    bitmap, count = mc.verify_batch_dev(shards, [rsv.PcsConfig(*rsv._cfg_key(c)) for c in table])
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
+    assert np.array_equal(sharding.unpack_bitmap(bitmap, n), oacc) and count == int(oacc.sum())
+    assert np.array_equal(shards[0]["d_accept"].cpu().numpy(), oacc[:37]) and np.array_equal(shards[0]["d_reason"].cpu().numpy(), oreason[:37])
+    assert np.array_equal(shards[2]["d_reason"].cpu().numpy(), oreason[37:])
+    # the Python exchange on the same job (world 1: its slice is the whole bitmap)
+    blob, offsets = rsv.pack(proofs)
+    d_blob, d_off = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    sv = sharding.ShardedVerifier(rsv, n, 0, 1, 0, dist, torch)
+    sv.step(d_blob, d_off, sv.ctx.prepare_cfg(cfgs, n))
+    sv.synchronize()
+    assert np.array_equal(sv.exchange.gathered.cpu().numpy().view(np.uint32)[: len(bitmap)], bitmap)
+    assert sv.exchange.total_accepted() == count
+    sv.close()
+    mc.close()
+
+
+def test_multi_argument_validation(rsv):
+    import ctypes
+    lib = rsv.lib
+    h = ctypes.c_void_p()
+    assert lib.rsv_multi_create(None, 1, ctypes.byref(h)) == -1
+    assert lib.rsv_multi_create((ctypes.c_int * 1)(0), 0, ctypes.byref(h)) == -2
+    assert lib.rsv_multi_create((ctypes.c_int * 2)(0, 99), 2, ctypes.byref(h)) == -3 and not h.value   # no such device: nothing leaks
+    mc = rsv.MultiContext([0, 0])
+    acc, reason, bitmap, count = mc.verify_batch_host([], fixture_cfg_std())
+    assert len(acc) == 0 and count == 0
+    with pytest.raises(ValueError):
+        mc.verify_batch_dev([{"d_blob": None, "d_offsets": None, "n": 0}], [rsv.PcsConfig(20, 5, 8, 16)])
+    assert lib.rsv_multi_ctx(mc._h, 2) is None and lib.rsv_multi_ctx(mc._h, 1) is not None
+    mc.close()
+
+
+EXCHANGE_RANK = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["RSV_ROOT"])
+import rsvload
+rsv = rsvload.load_package()
+import torch
+from tests import oracle_binding as ob
+from tests.conftest import read_proof, fixture_cfg
+
+# the one-process-per-GPU exchange through the C-ABI (rsv_exchange_*: ncclAllGather + ncclAllReduce bound at run time),
+# no torch.distributed anywhere: world size 1 on the one GPU of the box
+assert rsv.exchange_available()
+dev = torch.device("cuda:0")
+proof = read_proof("recursive_proof_16_15.bin")
+n = 333
+batch = [ob.tamper(proof, i) if i % 9 == 4 else proof for i in range(n)]
+blob, offsets = rsv.pack(batch)
+d_blob = torch.from_numpy(blob.copy()).to(dev)
+d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+ctx = rsv.Context(0)
+uid = rsv.exchange_unique_id()
+ex = rsv.Exchange(ctx, uid, 0, 1, n)
+assert (ex.lo, ex.hi, ex.slice_words) == (0, n, (n + 31) // 32)
+d_local = torch.full((ex.slice_words,), -1, dtype=torch.int32, device=dev)
+d_gathered = torch.zeros((1, ex.slice_words), dtype=torch.int32, device=dev)
+d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
+for _ in range(3):
+    ctx.verify_hints(d_blob, d_off, n, d_acc, cfg=fixture_cfg("recursive_proof_16_15.bin"), d_accept_bitmap=d_local, d_accept_count=d_count)
+    ex.run(d_local, d_gathered, d_count)
+ctx.synchronize()
+want = np.array([0 if i % 9 == 4 else 1 for i in range(n)], np.uint8)
+acc, bitmap = rsv.exchange_assemble(n, 1, d_gathered.cpu().numpy().view(np.uint32))
+print(json.dumps({"rccl": "ok", "version": rsv.lib.rsv_exchange_rccl_version(), "match": bool(np.array_equal(acc, want)),
+                  "count": int(d_count.item()), "want_count": int(want.sum())}))
+ex.close()
+ctx.close()
+'''
+
+
+def test_exchange_through_the_c_abi_world_one(tmp_path):
+    script = tmp_path / "exchange_rank.py"
+    script.write_text(EXCHANGE_RANK)
+    env = dict(os.environ, RSV_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rccl"] == "ok" and d["match"] and d["count"] == d["want_count"] and d["version"] > 0
+
+
+def test_bench_five_rank_rehearsal_odd_split():
+    """The widest rehearsal the box allows: at most 6 processes may hold the GPU, pytest is one of them, so FIVE ranks on
+    cuda:0 (gloo exchange) with a job that does not divide (5 003 proofs -> shards of 1 001 / 1 001 / 1 001 / 1 000 /
+    1 000).  World 8 with an odd split runs on the CPU in tests/test_sharding.py."""
+    d = _bench(["--gpus", "5", "--rehearsal", "--total-proofs", "5003", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
+    assert d["n_gpus"] == 5 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 5003 and d["config"]["proofs_rank0"] == 1001
+    ex = d["config"]["exchange"]
+    assert ex["world_size"] == 5 and sorted(x["rank"] for x in ex["devices"]) == [0, 1, 2, 3, 4] and len({x["pid"] for x in ex["devices"]}) == 5

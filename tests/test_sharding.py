@@ -99,7 +99,7 @@ def test_launcher_command_line(monkeypatch):
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("n_total,world", [(23, 2), (64, 2), (7, 3)])
+@pytest.mark.parametrize("n_total,world", [(23, 2), (64, 2), (7, 3), (83, 8), (5, 8)])
 def test_gloo_ranks_bitmap_exchange(n_total, world):
     import torch.multiprocessing as mp
     sh = load_sharding()
