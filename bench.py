@@ -120,18 +120,54 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_share():
+    """What the box lets this process use: logical CPUs, scheduler affinity, cgroup CPU quota.  A one-GPU slice of a
+    256-core host is capped well below os.cpu_count(): on the round-4 box cpu.max = "1600000 100000" = 16 CPUs, and 256
+    oracle threads verify FEWER proofs per second than 16 (3 231 against 4 107: the quota throttles them)."""
+    info = {"os_cpu_count": os.cpu_count()}
+    usable = os.cpu_count() or 1
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+        usable = min(usable, info["sched_affinity"])
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            info["cgroup_cpu_max"] = f.read().strip()
+        quota, period = info["cgroup_cpu_max"].split()
+        if quota != "max":
+            usable = min(usable, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            info["cgroup_cfs_quota_us"], info["cgroup_cfs_period_us"] = q, per
+            if q > 0:
+                usable = min(usable, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    info["usable_cpus"] = usable
+    return info
+
+
 def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
-    """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores: all of them (at most
-    16 threads, one shard of the sample each), then ONE thread on a sixteenth of the sample."""
+    """The C oracle (a port of the reference algorithm, not the Rust binary) on the host cores ("all host
+    cores").  Three legs, about 160 proofs per thread each (1-1.5 s):
+      value              every CPU this process may USE: min(logical CPUs, scheduler affinity, cgroup quota) threads
+      all_logical_cpus   os.cpu_count() threads, when that is more than the usable share (reported, so that nobody has
+                         to wonder what 256 threads would have given: less, the quota throttles them)
+      one_thread         one thread."""
     import ctypes
     from tests import oracle_binding as ob
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    share = cpu_share()
+    threads = share["usable_cpus"]
     n_sample = min(n_sample, len(offsets) - 1)
     pi = ob.make_inputs(ob.STANDARD_INPUTS)
     arr = (ob.PcsConfig * len(cfg_rows))(*[ob.PcsConfig(*r) for r in cfg_rows])
     of = np.ascontiguousarray(cfg_of[:n_sample], dtype=np.uint8)
 
     def run(n_run, n_threads):
+        n_threads = max(1, min(n_threads, n_run))
         bounds = np.linspace(0, n_run, n_threads + 1).astype(int)
 
         def work(t):
@@ -149,21 +185,30 @@ def cpu_baseline(blob_host, offsets, n_sample, cfg_rows, cfg_of, fixtures=None):
         t0 = time.perf_counter()
         with ThreadPoolExecutor(n_threads) as ex:
             accepted = sum(ex.map(work, range(n_threads)))
-        return time.perf_counter() - t0, accepted
+        return time.perf_counter() - t0, accepted, n_threads
 
-    dt, accepted = run(n_sample, threads)
-    n_one = max(1, n_sample // 16)
-    dt_one, _ = run(n_one, 1)
+    n_use = max(1, min(n_sample, 640 * threads))
+    dt, accepted, used = run(n_use, threads)
+    all_logical = None
+    logical = os.cpu_count() or 1
+    if logical > threads and n_sample >= 2 * threads:
+        n_all = max(1, min(n_sample, 40 * logical))
+        dt_all, _, used_all = run(n_all, logical)
+        all_logical = {"value": n_all / dt_all, "unit": "proofs/s", "cores": used_all, "proofs": n_all,
+                       "note": "one thread per logical CPU the host reports; the cgroup quota above throttles them"}
+    n_one = max(1, min(n_sample, 160))
+    dt_one, _, _ = run(n_one, 1)
     # Poseidon2 permutations the oracle's batched walk spends on the genuine fixtures of this workload (untimed): the
     # unit of useful work of this path, used for the in-situ permutation rate reported next to the microbenchmark
     perms = [ob.perm_count(read_fixture(f)) for f in fixtures] if fixtures else []
-    return {"value": n_sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": f"first {n_sample} proofs of the rank-0 batch ({accepted} accepted), C oracle, {threads} threads; "
-                      f"one_thread: the first {n_one} of them on 1 thread",
+    return {"value": n_use / dt, "unit": "proofs/s", "cores": used, "kind": "port",
+            "sample": f"first {n_use} proofs of the rank-0 batch ({accepted} accepted), C oracle, {used} threads = every CPU this "
+                      f"process may use (cpu_share: {logical} logical CPUs, usable {threads}); one_thread: the first {n_one} on 1 thread",
+            "all_logical_cpus": all_logical,
             "one_thread": {"value": n_one / dt_one, "unit": "proofs/s", "cores": 1},
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_cores": logical, "cpu_share": share,
             "note": "oracle/rsv_oracle.c: a plain scalar C restatement of the reference algorithm (not the Rust binary, which "
-                    "cannot be built here); a reported baseline, not a tuned CPU implementation",
+                    "cannot be built here; Mersenne-fold modular multiply, no SIMD); a reported baseline, not a tuned CPU implementation",
             "perms_per_proof": (sum(perms) / len(perms)) if perms else None}
 
 
@@ -367,6 +412,7 @@ def main():
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC bytes measured by tools/profile.sh on THESE kernel sources, else null.
     traffic, traffic_note = None, "traffic: no PMC profile of these kernel sources under profiles/ (tools/profile.sh writes pmc_latest.json)"
+    valu_issue_frac = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             prof = json.load(f)
@@ -376,22 +422,32 @@ def main():
         elif args.workload != "standard" or n != prof.get("proofs"):
             traffic_note = "traffic: profiles/pmc_latest.json holds the default workload only, not reported for this one"
         else:
-            traffic = float(prof["kernels"]["k_" + dom]["hbm_bytes_corrected"])
+            pk = prof["kernels"]["k_" + dom]
+            traffic = float(pk["hbm_bytes_corrected"])
+            # raw VALU issue of the dominant kernel: wave-level VALU instructions of the profiled launch over THIS run's
+            # kernel time, against one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz (the nominal rate)
+            if pk.get("SQ_INSTS_VALU") and dom_ms > 0:
+                valu_issue_frac = float(pk["SQ_INSTS_VALU"]) / (dom_ms * 1e-3) / (SIMDS * LAB_GHZ * 1e9 / 2.0)
             traffic_note = (f"traffic: HBM bytes of k_{dom} per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                             f"command on these kernel sources ({prof['tag']}), FETCH_SIZE doubled per MI355X_MICROARCH.md")
     except (OSError, KeyError, ValueError):
         pass
     pipeline_gbps = algo_bytes / (ms_per_step * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+    # `bound` says what really binds the dominant kernel: integer VALU issue (99.8 % of its instructions are the
+    # permutation).  achieved / peak / frac stay the tier's nominal HBM figure (algorithmic bytes over kernel time against
+    # 8 TB/s), as SURVEY 8d defines them; valu_issue_frac is the binding one.
+    roofline = {"bound": "valu", "nominal_bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue_frac": valu_issue_frac,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms,
                 "pipeline_ms": ms_per_step, "pipeline_GBps": pipeline_gbps, "pipeline_frac": pipeline_gbps / HBM_PEAK_GBPS,
                 "stage_ms": stage_avg,
                 "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY §8d); see valu. "
                         "frac charges the whole proof to the dominant kernel (SURVEY §8d's numerator); pipeline_frac "
-                        "is the same bytes over the wall time of a step on rank 0.  kernel_ms / stage_ms are HIP-event "
-                        "times on the verifier's streams; side-stream stages overlap the main stream, so stage_ms do not "
-                        "add up to pipeline_ms.  " + traffic_note}
+                        "is the same bytes over the wall time of a step on rank 0.  valu_issue_frac = SQ_INSTS_VALU of the "
+                        "profiled launch / kernel_ms / (1 024 SIMDs x 2.4 GHz / 2).  kernel_ms / stage_ms are HIP-event "
+                        "spans on the verifier's streams; side-stream stages overlap the main stream, so stage_ms do not "
+                        "add up to pipeline_ms, and a span includes the time a launch waits for room on the chip: "
+                        "'cap_top(span)' is ~0.5 ms of work that sits underneath the FRI trees for most of their duration.  " + traffic_note}
 
     # Poseidon2 microbench (second metric of BASELINE.json): 2^k states resident in HBM, 128 B per permutation
     valu = None
@@ -481,9 +537,8 @@ def main():
     host_path = None
     sample = args.cpu_sample
     if sample != 0 and world == 1:  # the CPU baseline is a single-GPU-run figure (rank 0 at N = 1 only)
-        threads = max(1, min(os.cpu_count() or 1, 16))
         if sample < 0:
-            sample = 640 * threads  # ~5 s per thread at ~8 ms per proof
+            sample = 10240  # the legs of cpu_baseline() and the host-path sample are cut from it
         n_s = min(sample, n)
         end = int(d_offsets[n_s].item())
         blob_host = d_blob[:end].cpu().numpy()
@@ -493,17 +548,18 @@ def main():
         offs_host = d_offsets[:n_s + 1].cpu().numpy()
         # PCIe-inclusive rate (never `value`): the same sample starting in HOST memory, one buffer per proof as the
         # reference's callers hold them, through rsv_verify_batch_host (gather -> pinned -> DMA -> verify, pipelined)
-        views = [blob_host[int(offs_host[i]):int(offs_host[i + 1])] for i in range(n_s)]
-        hcfg = [fcfg[k] for k in fix_idx[:n_s]] if len(set(rows)) > 1 else fcfg[0]
+        n_h = min(10240, n_s)  # the host-path sample of rounds 1-3 (1.2 GB); tools/host_path_bench.py sweeps sizes
+        views = [blob_host[int(offs_host[i]):int(offs_host[i + 1])] for i in range(n_h)]
+        hcfg = [fcfg[k] for k in fix_idx[:n_h]] if len(set(rows)) > 1 else fcfg[0]
         hb = rsv.HostBatch(views)  # the pointer table a Rust caller's Vec<Vec<u8>> already is
         ctx.verify_batch_host(hb, hcfg)  # untimed: the context's pinned staging ring is allocated on first use (~1 GB/s)
         th = time.perf_counter()
         hacc, _ = ctx.verify_batch_host(hb, hcfg)
         hdt = time.perf_counter() - th
-        if not np.array_equal(hacc, want[:n_s]):
+        if not np.array_equal(hacc, want[:n_h]):
             raise SystemExit("host path: verdict mismatch")
-        host_path = {"value": n_s / hdt, "unit": "proofs/s", "GBps": hb.bytes / hdt / 1e9, "proofs": n_s,
-                     "note": "rsv_verify_batch_host on the cpu_baseline sample, second call on the context: proofs start in "
+        host_path = {"value": n_h / hdt, "unit": "proofs/s", "GBps": hb.bytes / hdt / 1e9, "proofs": n_h,
+                     "note": "rsv_verify_batch_host on the first 10 240 proofs of the batch, second call on the context: proofs start in "
                              "pageable host memory, one buffer each; includes the gather into pinned memory, the PCIe upload, "
                              "the verdict download.  Never `value`."}
         cpu = cpu_baseline(blob_host, offs_host, n_s, table, of, fixtures)

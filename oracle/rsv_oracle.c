@@ -10,7 +10,7 @@
  * lane-per-path kernels so the two cross-check each other.
  *
  * Parity: pinned by the Poseidon2 KAT and by acceptance of the reference's 15
- * Poseidon-channel fixtures (tests/test_oracle_fixtures.py).
+ * Poseidon-channel fixtures (tests/test_oracle.py).
  */
 #include "rsv_oracle.h"
 
@@ -32,7 +32,15 @@ typedef struct { cm31 a, b; } qm31; /* a + b*u,  u^2 = 2 + i */
 static inline m31 m_add(m31 x, m31 y) { uint32_t s = x + y; return s >= P ? s - P : s; }
 static inline m31 m_sub(m31 x, m31 y) { return x >= y ? x - y : x + P - y; }
 static inline m31 m_neg(m31 x) { return x ? P - x : 0; }
-static inline m31 m_mul(m31 x, m31 y) { return (m31)(((uint64_t)x * y) % P); }
+/* Mersenne fold (2^31 = 1 mod P) instead of a division: what any tuned CPU implementation does, so that the CPU baseline
+ * timed from this file is not handicapped by `% P`.  Correct for ANY 32-bit operands (words >= P can reach here only
+ * on paths that reject them afterwards): t < 2^64, first fold < 2^34, second fold <= P + 7. */
+static inline m31 m_mul(m31 x, m31 y) {
+    uint64_t t = (uint64_t)x * y;
+    uint64_t f = (t & P) + (t >> 31);
+    uint32_t r = (uint32_t)(f & P) + (uint32_t)(f >> 31);
+    return r >= P ? r - P : r;
+}
 static m31 m_pow(m31 x, uint32_t e) {
     m31 r = 1;
     while (e) { if (e & 1) r = m_mul(r, x); x = m_mul(x, x); e >>= 1; }
