@@ -4,10 +4,11 @@
 // stwo's M31/CM31/QM31 inside M31Var/CM31Var/QM31Var; only the `value` half is
 // reproduced here).  All inputs and outputs are canonical words in [0, P).
 //
-// CDNA4 notes: a 31x31->62 bit product is one quarter-rate v_mad_u64_u32; the
-// Mersenne fold is v_alignbit + v_and + v_add, and the final conditional
-// subtract is the branch-free `min(s, s - P)` (v_subrev + v_min_u32).  No
-// 64-bit adds, no divides, no MFMA (31-bit modular integer work).
+// CDNA4 notes: a 31x31->62 bit product is one v_mad_u64_u32 (measured 4.5-5 cycles per wave-instruction per SIMD on
+// gfx950: the same class as v_min / v_alignbit, NOT quarter rate — poseidon2.hpp has the table); the Mersenne fold is
+// v_alignbit + v_and + v_add, and the final conditional subtract is the branch-free `min(s, s - P)` (v_subrev +
+// v_min_u32).  No divides, no MFMA (31-bit modular integer work).  These are the CANONICAL forms (inputs and outputs in
+// [0, P)); the permutation's hot paths carry weakly reduced values instead (poseidon2.hpp, poseidon2_row.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
