@@ -152,14 +152,29 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                     else off = lvl_nd(h->lvl[mx]) * nc_leaf + ent_rb(ent[cl * G + j]) * nc;
                     bool inb = off + nc <= qv_n;
                     if (!inb) flags |= 1u << (R_MERKLE_T0 + t);
-                    for (uint32_t k = 0; k < nc; k++) {
-                        uint32_t v = inb ? qv[off + k] : 0u;
-                        r0 = q_add(r0, q_mul_m(ldq(c->apow[col]), v));
-                        if (t == 2 && (k & 4)) {
-                            r1 = q_add(r1, q_mul_m(ldq(c->apow[ncols_group + dbl]), v));
-                            dbl++;
+                    // Four columns at a time, every load of the four issued before the first product: one load per
+                    // iteration is consumed at once, and the lane then pays the whole memory latency 134 times (a single
+                    // proof: 0.11 ms of a 1.3 ms call).  Interaction columns 4-7 / 12-15 (k & 4) carry a second sample
+                    // point: a batch starts at a multiple of 4, so a whole batch has one or none.
+                    for (uint32_t k0 = 0; k0 < nc; k0 += 4) {
+                        const bool twice = t == 2 && (k0 & 4);
+                        uint32_t vv[4];
+                        QM31 aa[4], bb[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            const bool ok = k0 + u < nc;
+                            vv[u] = (ok && inb) ? qv[off + k0 + u] : 0u;          // (a column beyond nc contributes 0)
+                            aa[u] = ldq(c->apow[ok ? col + u : col]);
+                            if (twice) bb[u] = ldq(c->apow[ncols_group + dbl + (ok ? u : 0u)]);
                         }
-                        col++;
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            r0 = q_add(r0, q_mul_m(aa[u], vv[u]));
+                            if (twice) r1 = q_add(r1, q_mul_m(bb[u], vv[u]));
+                        }
+                        const uint32_t done = nc - k0 < 4 ? nc - k0 : 4u;
+                        col += done;
+                        if (twice) dbl += done;
                     }
                 }
             }
