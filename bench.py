@@ -562,6 +562,20 @@ def main():
                      "note": "rsv_verify_batch_host on the first 10 240 proofs of the batch, second call on the context: proofs start in "
                              "pageable host memory, one buffer each; includes the gather into pinned memory, the PCIe upload, "
                              "the verdict download.  Never `value`."}
+        # the caller that cooperates: the same proofs read back to back into the library's pinned arena (rsv_host_alloc):
+        # the DMA engine uploads every chunk from where it is, no gather copy
+        arena = rsv.HostArena(hb.bytes + 4096)
+        ha = arena.pack(views)
+        ctx.verify_batch_host(ha, hcfg)
+        th = time.perf_counter()
+        aacc, _ = ctx.verify_batch_host(ha, hcfg)
+        adt = time.perf_counter() - th
+        if not np.array_equal(aacc, want[:n_h]):
+            raise SystemExit("host path (pinned arena): verdict mismatch")
+        host_path["pinned_arena"] = {"value": n_h / adt, "unit": "proofs/s", "GBps": ha.bytes / adt / 1e9,
+                                     "note": "the same proofs held back to back in rsv_host_alloc memory: uploaded from where they are"}
+        del ha
+        arena.close()
         cpu = cpu_baseline(blob_host, offs_host, n_s, table, of, fixtures)
         if witness is not None:
             # the witness leg's CPU baseline: the oracle's restatement of the circuit (Python integers) on ONE proof, one thread

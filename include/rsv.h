@@ -334,6 +334,14 @@ int rsv_verify_batch_dev(rsv_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_
 int rsv_verify_batch_host(rsv_ctx* ctx, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
                           const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
                           uint8_t* reason);
+/* Pinned host memory for proofs.  A caller that can cooperate reads / deserialises its proofs straight into such an
+ * arena, back to back in job order: rsv_verify_batch_host (and rsv_multi_verify_batch_host) then recognise every chunk
+ * whose proofs lie contiguously inside one arena and let the DMA engine upload it from where it is — no gather copy, no
+ * staging ring (the pinned ring is not even allocated when the whole job qualifies).  Anything else (pageable memory,
+ * gaps, proofs out of order) goes through the gather as before; the two mix freely chunk by chunk.  hipHostMalloc is
+ * slow (about 1 GB/s): allocate once, reuse.  rsv_host_free ignores pointers this library did not hand out. */
+int rsv_host_alloc(size_t bytes, void** out);
+void rsv_host_free(void* p);
 
 /* ---- SURVEY 8f.1 (next row): per-query authentication paths -----------------
  * Emits, while verifying, the per-query Merkle paths of the four commitment trees in TRANSCRIPT query order —

@@ -209,6 +209,8 @@ def _load() -> ctypes.CDLL:
         "rsv_witness_eval_dev": (ctypes.c_int, [vp, vp, vp, vp, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, vp, vp, vp, vp, vp]),
         "rsv_witness_eval": (ctypes.c_int, [vp, _u8p, _u64p, sz, ctypes.POINTER(CfgSet), ctypes.POINTER(PublicInput), sz, _u32p, _u32p, _u8p,
                                             _u8p, _u8p, ctypes.c_int]),
+        "rsv_host_alloc": (ctypes.c_int, [sz, ctypes.POINTER(vp)]),
+        "rsv_host_free": (None, [vp]),
         "rsv_shard_range": (None, [sz, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
         "rsv_multi_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), sz, ctypes.POINTER(vp)]),
         "rsv_multi_destroy": (None, [vp]),
@@ -245,7 +247,7 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_transcript_batch", "rsv_poseidon_flow_count", "rsv_witness_program_create", "rsv_witness_program_destroy",
            "rsv_witness_program_build", "rsv_witness_program_info", "rsv_witness_program_export", "rsv_witness_program_gates",
            "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval",
-           "rsv_shard_range", "rsv_multi_create", "rsv_multi_destroy", "rsv_multi_size", "rsv_multi_ctx", "rsv_multi_verify_batch_host",
+           "rsv_host_alloc", "rsv_host_free", "rsv_shard_range", "rsv_multi_create", "rsv_multi_destroy", "rsv_multi_size", "rsv_multi_ctx", "rsv_multi_verify_batch_host",
            "rsv_multi_verify_batch_dev", "rsv_exchange_available", "rsv_exchange_rccl_version", "rsv_exchange_unique_id",
            "rsv_exchange_create", "rsv_exchange_destroy", "rsv_exchange_layout", "rsv_exchange_run", "rsv_exchange_assemble"]
 
@@ -675,6 +677,42 @@ def fri_paths(proofs: Sequence[bytes], cfg, n_queries: int, max_log: int, n_inne
                              max_log, n_inner, sib.ctypes.data_as(_u32p), cols.ctypes.data_as(_u32p),
                              accept.ctypes.data_as(_u8p), reason.ctypes.data_as(_u8p), device), "rsv_fri_paths")
     return sib, cols, accept, reason
+
+
+class HostArena:
+    """rsv_host_alloc: pinned host memory the caller reads its proofs into, back to back; `buf` is a numpy uint8 view of it.
+    pack(proofs) copies a list of proofs in and returns the HostBatch over the copies (what a caller that deserialises
+    straight into the arena would hold)."""
+
+    def __init__(self, nbytes: int):
+        h = ctypes.c_void_p()
+        _check(lib.rsv_host_alloc(nbytes, ctypes.byref(h)), "rsv_host_alloc")
+        self._h = h
+        self.nbytes = nbytes
+        self.buf = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(h.value))
+
+    def pack(self, proofs) -> "HostBatch":
+        views, at = [], 0
+        for p in proofs:
+            a = np.frombuffer(p, dtype=np.uint8) if not isinstance(p, np.ndarray) else p
+            if at + a.size > self.nbytes:
+                raise ValueError("arena too small")
+            self.buf[at:at + a.size] = a
+            views.append(self.buf[at:at + a.size])
+            at += a.size
+        return HostBatch(views)
+
+    def close(self):
+        if self._h:
+            self.buf = None
+            lib.rsv_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostBatch:

@@ -78,6 +78,7 @@ __device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n
 // folding/src/lib.rs:194-204: the folded value of a query must equal the last-layer polynomial at its point
 __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q_eq(eval, folded); }
 
+constexpr uint32_t QB = 2;  // columns per batch of loads in k_query (4 = a multiple of the interaction columns' period; 2 keeps 5 waves per SIMD)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     __shared__ uint32_t xq[BLOCK][4];
@@ -156,23 +157,25 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                     // iteration is consumed at once, and the lane then pays the whole memory latency 134 times (a single
                     // proof: 0.11 ms of a 1.3 ms call).  Interaction columns 4-7 / 12-15 (k & 4) carry a second sample
                     // point: a batch starts at a multiple of 4, so a whole batch has one or none.
-                    for (uint32_t k0 = 0; k0 < nc; k0 += 4) {
+                    for (uint32_t k0 = 0; k0 < nc; k0 += QB) {
                         const bool twice = t == 2 && (k0 & 4);
-                        uint32_t vv[4];
-                        QM31 aa[4], bb[4];
+                        uint32_t vv[QB];
+                        QM31 aa[QB];
 #pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
+                        for (uint32_t u = 0; u < QB; u++) {
                             const bool ok = k0 + u < nc;
                             vv[u] = (ok && inb) ? qv[off + k0 + u] : 0u;          // (a column beyond nc contributes 0)
                             aa[u] = ldq(c->apow[ok ? col + u : col]);
-                            if (twice) bb[u] = ldq(c->apow[ncols_group + dbl + (ok ? u : 0u)]);
                         }
 #pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            r0 = q_add(r0, q_mul_m(aa[u], vv[u]));
-                            if (twice) r1 = q_add(r1, q_mul_m(bb[u], vv[u]));
+                        for (uint32_t u = 0; u < QB; u++) r0 = q_add(r0, q_mul_m(aa[u], vv[u]));
+                        if (twice) {  // the second sample point's powers in the same registers (keeps the kernel at 5 waves per SIMD)
+#pragma unroll
+                            for (uint32_t u = 0; u < QB; u++) aa[u] = ldq(c->apow[ncols_group + dbl + (k0 + u < nc ? u : 0u)]);
+#pragma unroll
+                            for (uint32_t u = 0; u < QB; u++) r1 = q_add(r1, q_mul_m(aa[u], vv[u]));
                         }
-                        const uint32_t done = nc - k0 < 4 ? nc - k0 : 4u;
+                        const uint32_t done = nc - k0 < QB ? nc - k0 : QB;
                         col += done;
                         if (twice) dbl += done;
                     }

@@ -817,6 +817,51 @@ def test_verify_batch_host_pipeline(rsv, manifest, chunk_mb):
     ctx.close()
 
 
+@pytest.mark.parametrize("chunk_mb", [1, 256])
+def test_verify_batch_host_from_a_pinned_arena(rsv, manifest, chunk_mb):
+    """rsv_host_alloc: proofs read back to back into the library's pinned arena are uploaded from where they are (no
+    gather copy); chunks that do not qualify — a proof outside the arena, a gap, a buffer that is not a whole number of
+    words — take the gather path, the two mixed chunk by chunk in one call.  Verdicts and reasons == the oracle's either
+    way, and == the plain path's."""
+    proofs, cfgs = [], []
+    for e in manifest:
+        pr = read_proof(e["file"])
+        if entry_inputs(e) == list(rsv.STANDARD_INPUTS):
+            proofs += [pr, ob.tamper(pr, len(proofs)), pr]
+            cfgs += [fixture_cfg(e["file"])] * 3
+    arena = rsv.HostArena(sum(len(p) for p in proofs) + 4096)
+    hb = arena.pack(proofs)                      # every proof inside the arena, contiguous in job order
+    ctx = rsv.Context(0)
+    ctx.set_option("host_chunk_mb", chunk_mb)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
+    acc, reason = ctx.verify_batch_host(hb, cfgs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist() and int(acc.sum()) > 10
+    # the same job with every fifth proof held OUTSIDE the arena (pageable memory) and one odd-length buffer inside it
+    mixed = list(hb.keep)
+    for i in range(2, len(mixed), 5):
+        mixed[i] = np.frombuffer(proofs[i], dtype=np.uint8).copy()
+    acc2, reason2 = ctx.verify_batch_host(mixed, cfgs)
+    assert acc2.tolist() == oacc.tolist() and reason2.tolist() == oreason.tolist()
+    odd = list(hb.keep)
+    odd[1] = odd[1][:len(odd[1]) - 2]           # not a whole number of words: RSV_R_PARSE, neighbours unaffected
+    acc3, reason3 = ctx.verify_batch_host(odd, cfgs)
+    want3, wantr3 = oacc.copy(), oreason.copy()
+    want3[1], wantr3[1] = 0, 1
+    assert acc3.tolist() == want3.tolist() and reason3.tolist() == wantr3.tolist()
+    # proofs in the arena but NOT in job order (reversed): contiguity fails, the gather path takes them
+    rev = list(reversed(hb.keep))
+    acc4, reason4 = ctx.verify_batch_host(rev, list(reversed(cfgs)))
+    assert acc4.tolist() == oacc[::-1].tolist() and reason4.tolist() == oreason[::-1].tolist()
+    # through the multi-context entry point as well (three contexts on the one device)
+    mc = rsv.MultiContext([0, 0, 0])
+    acc5, reason5, _, count5 = mc.verify_batch_host(hb, cfgs)
+    assert acc5.tolist() == oacc.tolist() and reason5.tolist() == oreason.tolist() and count5 == int(oacc.sum())
+    mc.close()
+    ctx.close()
+    arena.close()
+    assert rsv.lib.rsv_host_alloc(0, None) == -1 and rsv.lib.rsv_host_free(None) is None
+
+
 def test_mutant_corpus_matches_oracle(rsv, manifest):
     """Parity fuzz: structural mutants, every length prefix perturbed, random byte corruption and truncations of
     six fixtures of different shapes (n_queries 8..80) in ONE mixed batch: verdict and reason == oracle's."""

@@ -46,6 +46,21 @@ def main():
         dt = time.perf_counter() - t0
         assert rc == 0 and int(acc.sum()) == n - len(range(5, n, 17))
         out[label] = {"s": dt, "proofs_per_s": n / dt, "GBps": total / dt / 1e9}
+    # the caller that cooperates: proofs read back to back into the library's pinned arena (rsv_host_alloc) — no gather copy
+    arena = rsv.HostArena(total + 4096)
+    t0 = time.perf_counter()
+    hb = arena.pack(proofs)
+    out["arena_fill_s"] = time.perf_counter() - t0   # (the caller's own read / deserialisation, not part of the call)
+    lens_a = hb.lens
+    for label, mb in (("arena_direct_64MB", 64), ("arena_direct_128MB", 128), ("arena_direct_256MB", 256), ("arena_direct_256MB_again", 256)):
+        ctx.set_option("host_chunk_mb", mb)
+        acc[:] = 0
+        t0 = time.perf_counter()
+        rc = rsv.lib.rsv_verify_batch_host(ctx._h, hb.ptrs, lens_a.ctypes.data_as(u64p), n, pc.ref(), pi, 3, acc.ctypes.data_as(u8p), None)
+        dt = time.perf_counter() - t0
+        assert rc == 0 and int(acc.sum()) == n - len(range(5, n, 17))
+        out[label] = {"s": dt, "proofs_per_s": n / dt, "GBps": total / dt / 1e9}
+    arena.close()
     blob = np.concatenate(proofs)
     offsets = np.zeros(n + 1, np.uint64)
     offsets[1:] = np.cumsum([p.size for p in proofs], dtype=np.uint64)
