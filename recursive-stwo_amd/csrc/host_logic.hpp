@@ -1,0 +1,163 @@
+// host_logic.hpp — the HOST-side decisions of a verify call that touch no device: how a mixed batch is bucketed by
+// shape, and how the per-query stages are cut into groups that fit the workspace budget.  Plain C++ (no HIP): included by
+// verify_api.inc, and compiled on its own by g++ with AddressSanitizer + UBSan for tests/host_logic_asan.cpp, which drives
+// it from recorded and adversarial shape arrays — the host code of the mixed-batch path had never seen a sanitizer
+// before round 4 (the r3a crash pointed at exactly this code or at the test's own threads).
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+#include "layout.hpp"
+
+namespace rsv::host {
+
+// workspace carving: 256-byte aligned sub-allocations of one buffer (base == nullptr: size probe)
+struct Carve {
+    char* base;
+    size_t off = 0;
+    template <class T> T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += sizeof(T) * count;
+        return p;
+    }
+};
+
+// One launch geometry: every proof of a bucket has n_queries = G.  maxM / maxInner / minLevel bound its trees.
+struct Bucket { uint32_t G, maxM, maxInner, minLevel, count; size_t first; };
+
+// The parser's two shape words per proof (k_parse.hpp): word0 = n_queries | M << 8 | n_inner << 16 | min level << 24 (0: the
+// proof was rejected, no lane anywhere), word1 = the tree geometry.  Mixed batch: one bucket per n_queries; inside a bucket
+// the slots are ordered by shape class, so that the lanes of a wavefront (and nearly every workgroup) walk trees of one
+// geometry.  ids: slot -> proof.  cls / scratch: caller-owned (reused call after call).
+inline void bucket_by_shape(const uint32_t* shape, uint32_t N, std::vector<Bucket>& buckets, std::vector<uint32_t>& ids,
+                            std::vector<uint32_t>& cls) {
+    struct Class { uint32_t w0, w1, count; size_t start; };
+    std::vector<Class> classes;
+    std::unordered_map<uint64_t, uint32_t> class_of;  // hashed lookup: an adversarial batch may carry thousands of distinct shapes
+    buckets.clear();
+    cls.resize(N);
+    uint32_t last_w0 = 0, last_w1 = 0, last_c = 0;
+    for (uint32_t p = 0; p < N; p++) {
+        const uint32_t w0 = shape[2 * (size_t)p], w1 = shape[2 * (size_t)p + 1];
+        if (!w0) { cls[p] = 0xFFFFFFFFu; continue; }
+        uint32_t ci;
+        if (!classes.empty() && w0 == last_w0 && w1 == last_w1) ci = last_c;
+        else {
+            auto it = class_of.find(((uint64_t)w0 << 32) | w1);
+            if (it != class_of.end()) ci = it->second;
+            else {
+                ci = (uint32_t)classes.size();
+                class_of.emplace(((uint64_t)w0 << 32) | w1, ci);
+                classes.push_back({w0, w1, 0, 0});
+            }
+            last_w0 = w0; last_w1 = w1; last_c = ci;
+        }
+        cls[p] = ci;
+        classes[ci].count++;
+    }
+    // class order: by n_queries, then by the shape words
+    std::vector<uint32_t> order(classes.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const Class &a = classes[x], &b = classes[y];
+        if ((a.w0 & 0xFFu) != (b.w0 & 0xFFu)) return (a.w0 & 0xFFu) < (b.w0 & 0xFFu);
+        if (a.w0 != b.w0) return a.w0 < b.w0;
+        return a.w1 < b.w1;
+    });
+    size_t at = 0;
+    for (uint32_t ci : order) {
+        Class& c2 = classes[ci];
+        c2.start = at;
+        at += c2.count;
+        const uint32_t q = c2.w0 & 0xFFu;
+        if (buckets.empty() || buckets.back().G != q) buckets.push_back({q, 0, 0, 255, 0, c2.start});
+        Bucket& b = buckets.back();
+        b.maxM = std::max(b.maxM, (c2.w0 >> 8) & 0xFFu);
+        b.maxInner = std::max(b.maxInner, (c2.w0 >> 16) & 0xFFu);
+        b.minLevel = std::min(b.minLevel, c2.w0 >> 24);
+        b.count += c2.count;
+    }
+    ids.resize(at);
+    std::vector<size_t> fill(classes.size());
+    for (size_t i = 0; i < classes.size(); i++) fill[i] = classes[i].start;
+    for (uint32_t p = 0; p < N; p++)
+        if (cls[p] != 0xFFFFFFFFu) ids[fill[cls[p]]++] = p;
+}
+
+// One (bucket, slot range) of a group: cn slots of bucket bi from slot c0 on, launched with G lanes per proof, the dense
+// top-of-tree cap from level Lc down, its last Lt levels in k_cap_top (0: inside the tree kernels).
+struct Entry { size_t bi; size_t c0; uint32_t cn, G, Lc, Lt; size_t bytes; };
+
+struct GroupPolicy {
+    size_t budget;         // bytes of per-query workspace a group may use
+    size_t max_fused;      // entries per launch (Fused<>)
+    bool tree_cap_off;     // RSV_OPT_TREE_CAP = 2
+    bool flow;             // the pass writes PoseidonFlow records
+    bool flow_cap_off;     // RSV_OPT_FLOW_CAP = 2
+    bool cap_top;          // the last levels of the cap in k_cap_top
+};
+
+// per-query workspace of cn slots of a bucket (what verify_impl carves for one Entry)
+inline size_t entry_bytes(const Bucket& b, uint32_t G, size_t cn, uint32_t Lt) {
+    Carve probe{nullptr};
+    probe.take<PlanHdr>(cn);
+    probe.take<uint32_t>(cn * (b.maxM + 1) * G);
+    probe.take<uint32_t>(cn * 2 * G);
+    probe.take<uint32_t>(cn * (3 + b.maxInner) * G * 8);
+    if (Lt) {
+        probe.take<uint32_t>((cn * 4 << Lt) * 8);
+        probe.take<uint32_t>(cn * 4);
+        probe.take<uint32_t>((cn * (1 + b.maxInner) << Lt) * 8);
+        probe.take<uint32_t>(cn * (1 + b.maxInner));
+    }
+    return ((probe.off + 255) & ~(size_t)255) + 256;
+}
+
+// The batch is cut into GROUPS of at most max_fused entries whose workspaces fit the budget together; a group is ONE launch
+// per stage.  A uniform batch is one entry (several groups only when it exceeds the budget), a mixed batch normally one
+// group with an entry per n_queries.  Returns the workspace bytes the largest group needs.
+inline size_t plan_groups(const std::vector<Bucket>& buckets, const GroupPolicy& pol, std::vector<std::vector<Entry>>& groups) {
+    groups.clear();
+    size_t need = 0;
+    std::vector<Entry> cur;
+    size_t used = 0;
+    auto flush = [&]() { if (!cur.empty()) { groups.push_back(cur); need = std::max(need, used); cur.clear(); used = 0; } };
+    // widest buckets first: their workgroups are the longest-running, and a launch's tail should be short ones
+    for (size_t bk = buckets.size(); bk-- > 0;) {
+        const size_t bi = bk;
+        const Bucket& b = buckets[bi];
+        const uint32_t G = b.G < 4 ? 4u : b.G;  // pad tiny query counts so that a workgroup holds at most 64 proofs
+        // cap level: 2^Lc <= G and Lc strictly below every tree's lowest leaf / data level
+        uint32_t Lc = 0;
+        while ((2u << Lc) <= G) Lc++;
+        if (b.minLevel < 2) Lc = 0;
+        else if (Lc > b.minLevel - 1) Lc = b.minLevel - 1;
+        if (Lc > 6) Lc = 6;
+        if (Lc < 2) Lc = 0;
+        if (pol.tree_cap_off) Lc = 0;
+        if (pol.flow && pol.flow_cap_off) Lc = 0;  // every lane walks (and records) its whole path
+        const uint32_t Lt = (pol.cap_top && !pol.flow && Lc >= 3) ? (Lc >= 6 ? 3u : 2u) : 0u;  // k_cap_top writes no records
+        const size_t per_slot = entry_bytes(b, G, 1024, Lt) / 1024 + 1;
+        for (size_t c0 = 0; c0 < b.count;) {
+            size_t room = pol.budget > used ? (pol.budget - used) / per_slot : 0;
+            size_t cn = std::min<size_t>(b.count - c0, room);
+            if (cn < std::min<size_t>(b.count - c0, 1024)) {  // not worth a sliver: start a new group
+                if (!cur.empty()) { flush(); continue; }
+                cn = std::min<size_t>(b.count - c0, 1024);       // a budget below 1 024 slots: take them anyway
+            }
+            Entry en{bi, c0, (uint32_t)cn, G, Lc, Lt, entry_bytes(b, G, cn, Lt)};
+            cur.push_back(en);
+            used += en.bytes;
+            c0 += cn;
+            if (cur.size() == pol.max_fused) flush();
+        }
+    }
+    flush();
+    return need;
+}
+
+}  // namespace rsv::host

@@ -78,8 +78,11 @@ __device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n
 // folding/src/lib.rs:194-204: the folded value of a query must equal the last-layer polynomial at its point
 __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q_eq(eval, folded); }
 
-constexpr uint32_t QB = 2;  // columns per batch of loads in k_query (4 = a multiple of the interaction columns' period; 2 keeps 5 waves per SIMD)
-template <int BLOCK>
+// QB: columns per batch of loads (1, 2 or 4: a divisor of the interaction columns' period).  4 is the latency form (small
+// batches, where this kernel is on the step's chain of dependent kernels: 1 024 proofs 1.556 -> 1.532 ms) at 104-114
+// registers = 4 waves per SIMD; 2 keeps 96 registers = 5 waves per SIMD for the large batches that run it underneath the
+// trace trees (65 536 proofs: 34.13 ms against 34.87 with 4).
+template <int BLOCK, uint32_t QB>
 __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     __shared__ uint32_t xq[BLOCK][4];
     // The FRI trees wait for this kernel while it shares the machine with the trace trees: its waves go first in the

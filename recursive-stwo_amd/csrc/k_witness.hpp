@@ -13,11 +13,7 @@
 
 namespace rsv {
 
-enum WitnessOp : uint32_t {
-    W_CONST, W_ADD, W_MUL, W_MULC, W_COPY, W_INV, W_INV0, W_QINV, W_CINV, W_COORD, W_BIT, W_FLOW, W_WORD, W_WORD4,
-    W_FRI_COMMIT, W_LAST_POLY, W_NONCE, W_TRACE_COL, W_FRI_COL, W_N_OPS
-};
-
+// (enum WitnessOp: layout.hpp)
 struct WitnessArgs {
     const uint32_t* instr;  // [n_instr][8]: op, dst, a, b, imm0..3
     uint32_t begin, end;    // this level's instructions

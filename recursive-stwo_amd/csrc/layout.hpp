@@ -8,6 +8,13 @@
 #pragma once
 #include <stdint.h>
 
+// (this header and the host_*.hpp / circuit_*.hpp ones are plain C++: g++ builds them for the host-logic sanitizer pass,
+// tests/host_logic_asan.cpp, where the HIP qualifiers mean nothing)
+#if !defined(__HIPCC__) && !defined(__host__)
+#define __host__
+#define __device__
+#endif
+
 namespace rsv {
 
 constexpr int MAXQ = 128;      // max FRI queries per proof (fixtures: 8..80)
@@ -175,5 +182,11 @@ struct PlanHdr {
 };
 // fl[(d*G + j)] for the (up to two) non-leaf data levels d of the first-layer tree:
 //   w_self | w_sib << 16   (0xFFFF = none / sibling owned by lane SIB)
+
+// One instruction of a witness program (rsv_witness_program_*, k_witness.hpp) = 8 words: op, dst, a, b, imm0..3.
+enum WitnessOp : uint32_t {
+    W_CONST, W_ADD, W_MUL, W_MULC, W_COPY, W_INV, W_INV0, W_QINV, W_CINV, W_COORD, W_BIT, W_FLOW, W_WORD, W_WORD4,
+    W_FRI_COMMIT, W_LAST_POLY, W_NONCE, W_TRACE_COL, W_FRI_COL, W_N_OPS
+};
 
 }  // namespace rsv

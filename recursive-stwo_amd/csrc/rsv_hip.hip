@@ -24,6 +24,7 @@
 #include "primitives.hpp"
 #include "k_emulated.hpp"
 #include "verify.hpp"
+#include "host_logic.hpp"
 #include "k_witness.hpp"
 
 using namespace rsv;
@@ -481,6 +482,6 @@ int rsv_merkle_path_root(const uint32_t* query, const uint32_t* sib8, const uint
 #include "verify_api.inc"
 #include "host_stream.inc"
 #include "multi_api.inc"
+#include "circuit_program.hpp"
 #include "witness_api.inc"
-#include "circuit_verifier.hpp"
 #include "circuit_builder.inc"

@@ -10,8 +10,27 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _install_native_backtrace():
+    """A native stack trace on SIGSEGV & co. for the whole session (tests/native_backtrace.c): faulthandler alone names only
+    the Python frame, which is all that round 3's one host crash left behind.  Best effort: no compiler, no handler."""
+    import ctypes
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native_backtrace.c")
+    lib = os.path.join(ROOT, "tests", "native_backtrace.so")
+    try:
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", lib, src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        fd = os.dup(sys.__stderr__.fileno())  # (as pytest's own faulthandler plugin does: descriptor 2 is captured while tests run)
+        return ctypes.CDLL(lib).rsv_test_install_native_backtrace(fd) == 0
+    except (OSError, subprocess.CalledProcessError):
+        return False
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # behind pytest's own faulthandler plugin (which installed its handlers before conftest files are configured): ours
+    # runs first on a fatal signal and then chains to it
+    config._rsv_native_backtrace = _install_native_backtrace()
 
 
 def load_manifest():
