@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--rehearsal", action="store_true",
                     help="one-GPU box only: every rank on cuda:0, bitmap exchange over gloo (RCCL refuses two ranks on one "
                          "device).  The driver's runs never pass it: they use one GPU per rank and nccl (= RCCL).")
+    ap.add_argument("--no-single-proof", dest="single_proof", action="store_false",
+                    help="skip the single-proof latency leg (one proof per call, the reference's own use)")
     ap.add_argument("--emit-flow", action="store_true",
                     help="also emit the PoseidonFlow of every proof's verification circuit (SURVEY 8f.1, second half: 128 B + "
                          "1 B per Poseidon invocation, ~0.7 MB per standard proof) from the verifying pass; any workload")
@@ -449,6 +451,30 @@ def main():
                         "add up to pipeline_ms, and a span includes the time a launch waits for room on the chip: "
                         "'cap_top(span)' is ~0.5 ms of work that sits underneath the FRI trees for most of their duration.  " + traffic_note}
 
+    # What the reference's own use looks like: ONE proof per call (examples/single-proof/src/main.rs:23-82).  Latency of
+    # rsv_verify_batch_dev + rsv_ctx_synchronize for one proof resident in HBM, median of 30 calls: a chain of dependent
+    # kernels (233 transcript permutations, then ~25 per Merkle path), not a throughput figure.
+    single = None
+    if world == 1 and args.single_proof:
+        sp = read_fixture(fixtures[0])
+        d_sp = torch.from_numpy(np.frombuffer(sp, dtype=np.uint8).copy()).to(dev)
+        d_so = torch.tensor([0, len(sp)], dtype=torch.int64, device=dev)
+        d_sa = torch.zeros(1, dtype=torch.uint8, device=dev)
+        scfg = rsv.PreparedCfg([fcfg[0]])
+        lat = []
+        for k in range(35):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.verify_batch(d_sp, d_so, 1, d_sa, None, scfg)
+            ctx.synchronize()
+            if k >= 5:
+                lat.append(time.perf_counter() - t1)
+        if int(d_sa.item()) != 1:
+            raise SystemExit("single proof: a genuine fixture was not accepted")
+        lat.sort()
+        single = {"latency_ms": lat[len(lat) // 2] * 1e3, "min_ms": lat[0] * 1e3, "calls": len(lat), "fixture": fixtures[0],
+                  "note": "one proof per call, resident in HBM: rsv_verify_batch_dev + rsv_ctx_synchronize, median wall time"}
+
     # Poseidon2 microbench (second metric of BASELINE.json): 2^k states resident in HBM, 128 B per permutation
     valu = None
     if args.perm_log2 > 0:
@@ -613,7 +639,7 @@ def main():
                    "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
                        "gloo (rehearsal)" if rehearsal else ("nccl/RCCL" if world > 1 else "none (1 rank)")))},
         "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "valu": valu, "emulated_poseidon2": emulated,
-        "recursion_circuit_witness": witness,
+        "recursion_circuit_witness": witness, "single_proof": single,
     }
     print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -61,6 +61,8 @@ def test_bench_single_gpu_line():
     share = d["cpu_baseline"]["cpu_share"]
     assert share["usable_cpus"] >= 1 and d["cpu_baseline"]["cores"] == min(share["usable_cpus"], 64)
     assert d["host_path"]["value"] > 0 and d["host_path"]["GBps"] > 0  # PCIe-inclusive rate, reported beside `value`
+    assert d["host_path"]["pinned_arena"]["GBps"] > 0                   # the same from an rsv_host_alloc arena (no gather copy)
+    assert 0 < d["single_proof"]["min_ms"] <= d["single_proof"]["latency_ms"] < 50   # one proof per call: the reference's own use
     assert d["config"]["exchange"]["world_size"] == 1 and len(d["config"]["exchange"]["devices"]) == 1
     v = d["valu"]
     assert 0 < v["frac_of_ceiling"] <= 1.0 and 0 < v["pipeline_frac_of_ceiling"] <= 1.0

@@ -1146,14 +1146,19 @@ def test_query_values_match_oracle(rsv, manifest, name):
     d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_qv = torch.zeros((n, nq, 4 * (8 + n_inner)), dtype=torch.int32, device=dev)
     ctx = rsv.Context(0)
-    ctx.verify_hints(d_blob, d_off, n, d_acc, None, cfg=fixture_cfg(name), inputs=inputs, shape=(nq, M, n_inner), d_query_values=d_qv)
-    ctx.synchronize()
-    assert d_acc.cpu().numpy().tolist() == [1] * n
-    got = d_qv.cpu().numpy().view(np.uint32)
-    for k in range(n):
-        assert np.array_equal(got[k], want), k
-    ni = n_inner
-    assert np.array_equal(got[0][:, 24 + 4 * ni:28 + 4 * ni], got[0][:, 28 + 4 * ni:32 + 4 * ni])  # accept side of RSV_R_FRI_LAST
+    # both instantiations of k_query: the chain layout launches the latency form (four columns' loads in flight), the
+    # two-stream layout the one that runs beside the trace trees (two)
+    for layout in ("on", "off"):
+        ctx.set_option("critical_chain", layout)
+        d_qv.fill_(-1)
+        ctx.verify_hints(d_blob, d_off, n, d_acc, None, cfg=fixture_cfg(name), inputs=inputs, shape=(nq, M, n_inner), d_query_values=d_qv)
+        ctx.synchronize()
+        assert d_acc.cpu().numpy().tolist() == [1] * n
+        got = d_qv.cpu().numpy().view(np.uint32)
+        for k in range(n):
+            assert np.array_equal(got[k], want), (layout, k)
+        ni = n_inner
+        assert np.array_equal(got[0][:, 24 + 4 * ni:28 + 4 * ni], got[0][:, 28 + 4 * ni:32 + 4 * ni])  # accept side of RSV_R_FRI_LAST
     ctx.close()
 
 
