@@ -160,4 +160,63 @@ inline size_t plan_groups(const std::vector<Bucket>& buckets, const GroupPolicy&
     return need;
 }
 
+// Which FRI tree each grid row (blockIdx.y) of a SMALL k_pair_merkle launch hashes.  A launch whose workgroups are all
+// resident at once is not balanced by the dispatcher: workgroup i lands on compute unit i mod n_cu (round robin over the
+// XCDs, then inside them), so with `blocks` workgroups per grid row the rows pile up on the same compute units — 1 024
+// proofs of the standard shape are 64 x 9 workgroups: the first 64 compute units get rows 0, 4 and 8 (the first-layer tree
+// and two more: 67 path steps per SIMD), the others two rows (40-44), and the kernel lasts as long as the fullest.  The
+// trees differ in depth (first layer M + columns, inner layer i: M - 1 - i), so the host deals them out: compute units
+// that receive more rows get the shallowest trees, the rest longest-first onto the least loaded (LPT).  Identity when
+// the launch is larger than the machine holds (the dispatcher then balances by itself, longest trees first).
+// live: grid rows that have work (a single-configuration launch is sized for the deepest tree the parser admits, MAX_LOG: its
+// rows beyond the batch's real FRI layers exit at once and weigh nothing).
+inline void pair_layer_order(uint32_t blocks, uint32_t layers, uint32_t live, uint32_t M, uint32_t n_cu, uint32_t resident_per_cu, uint8_t* y_of) {
+    for (uint32_t k = 0; k < 32; k++) y_of[k] = (uint8_t)k;
+    if (live > layers) live = layers;
+    if (layers < 3 || live < 3 || layers > 32 || blocks == 0 || n_cu == 0 || (size_t)blocks * live > (size_t)n_cu * resident_per_cu || blocks >= n_cu) return;
+    // path steps of tree y (relative weights are what matters)
+    std::vector<uint32_t> len(layers);
+    for (uint32_t y = 0; y < layers; y++) len[y] = y >= live ? 0u : (y == 0 ? M + 8 : (M > y ? M - y : 1) + 4);
+    // rows per compute unit, and the compute units each grid position covers
+    std::vector<uint32_t> rows_of_cu(n_cu, 0), load(n_cu, 0);
+    auto first_cu = [&](uint32_t pos) { return (uint32_t)(((size_t)pos * blocks) % n_cu); };
+    for (uint32_t pos = 0; pos < layers; pos++)
+        for (uint32_t x = 0; x < blocks; x++) rows_of_cu[(first_cu(pos) + x) % n_cu]++;
+    std::vector<uint8_t> pos_used(layers, 0), tree_used(layers, 0);
+    std::vector<uint32_t> by_len(layers);
+    for (uint32_t y = 0; y < layers; y++) by_len[y] = y;
+    std::sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return len[a] != len[b] ? len[a] > len[b] : a < b; });  // longest first
+    auto assign = [&](uint32_t pos, uint32_t tree) {
+        y_of[pos] = (uint8_t)tree; pos_used[pos] = 1; tree_used[tree] = 1;
+        for (uint32_t x = 0; x < blocks; x++) load[(first_cu(pos) + x) % n_cu] += len[tree];
+    };
+    auto max_rows = [&](uint32_t pos) { uint32_t m = 0; for (uint32_t x = 0; x < blocks; x++) m = std::max(m, rows_of_cu[(first_cu(pos) + x) % n_cu]); return m; };
+    uint32_t min_rows = 0xFFFFFFFFu;
+    for (uint32_t c = 0; c < n_cu; c++) if (rows_of_cu[c]) min_rows = std::min(min_rows, rows_of_cu[c]);
+    // phase A: positions over compute units with more rows than the others take the shallowest trees, one per surplus row
+    std::vector<uint32_t> surplus_taken(n_cu, 0);
+    for (uint32_t pos = layers; pos-- > 0;) {
+        const uint32_t c0 = first_cu(pos);
+        if (max_rows(pos) > min_rows && surplus_taken[c0] + min_rows < rows_of_cu[c0]) {
+            uint32_t tree = 0xFFFFFFFFu;
+            for (uint32_t k = layers; k-- > 0;) if (!tree_used[by_len[k]]) { tree = by_len[k]; break; }  // shallowest left
+            assign(pos, tree);
+            for (uint32_t x = 0; x < blocks; x++) surplus_taken[(c0 + x) % n_cu]++;
+        }
+    }
+    // phase B: the rest longest-first onto the free position whose compute units carry least
+    for (uint32_t k = 0; k < layers; k++) {
+        const uint32_t tree = by_len[k];
+        if (tree_used[tree]) continue;
+        uint32_t best = 0xFFFFFFFFu, best_load = 0xFFFFFFFFu;
+        for (uint32_t pos = 0; pos < layers; pos++) {
+            if (pos_used[pos]) continue;
+            uint32_t m = 0;
+            for (uint32_t x = 0; x < blocks; x++) m = std::max(m, load[(first_cu(pos) + x) % n_cu]);
+            if (m < best_load) { best_load = m; best = pos; }
+        }
+        assign(best, tree);
+    }
+}
+
 }  // namespace rsv::host

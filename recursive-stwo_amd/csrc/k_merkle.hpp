@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
     const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
     const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
     const uint32_t slot_ = bx * per_block + grp;
-    const uint32_t slot = blockIdx.y;
+    const uint32_t slot = f.y_of[blockIdx.y];  // which FRI tree this grid row hashes (a permutation chosen by the host for small launches)
     bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;

@@ -32,6 +32,7 @@ struct Fused {
     uint32_t nb;
     uint32_t lds_proofs;                  // k_plan_par: proofs per workgroup its dynamic LDS tables are sized for
     uint32_t first_block[MAX_FUSED + 1];  // first blockIdx.x of set i; [nb] = grid size
+    uint8_t y_of[32];                     // k_pair_merkle: FRI tree of blockIdx.y (host_logic.hpp: pair_layer_order); identity elsewhere
     Args a[MAX_FUSED];
 };
 // dynamic LDS of k_plan_par for workgroups of up to `proofs` proofs

@@ -47,6 +47,7 @@ struct Options {
     int graph = 0;             // 0 / 2 off, 1 replay repeated identical calls as a HIP graph (experiment)
     int witness_layout = 0;    // 0 / 1 d_variables [proof][variable], 2 [variable][proof]
     int flow_cap = 0;          // PoseidonFlow passes: 0 / 1 top-of-tree cap (shared nodes hashed once), 2 every lane walks to the root
+    int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
     int witness_small_log = 0;        // 0 default, else 1 + log2(proofs per workgroup) of that form
@@ -77,6 +78,7 @@ static void destroy_graph_cache(GraphCache*);
 
 struct rsv_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // row hashes, quotient constants, k_query, FRI trees: underneath the main stream
     hipStream_t aux = nullptr;   // the front half of a small batch's transcript, next to the parser
@@ -157,6 +159,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
     if (!c) return RSV_E_DEVICE;
     c->device = device;
     c->opt = default_options();
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     // The side stream carries the kernels another stage waits for while they share the machine with a wider one (k_query
     // beside the trace trees): one dispatch priority level above normal where the device has one, a plain stream otherwise.
     auto create_side = [](hipStream_t* s) {
@@ -247,6 +250,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_WITNESS_LAYOUT: return tri(&o.witness_layout);
         case RSV_OPT_CAP_TOP: return tri(&o.cap_top);
         case RSV_OPT_FLOW_CAP: return tri(&o.flow_cap);
+        case RSV_OPT_PAIR_ORDER: return tri(&o.pair_order);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;
             o.witness_walk_log = (int)value; return RSV_OK;
