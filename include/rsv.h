@@ -422,10 +422,10 @@ int rsv_fri_paths(const uint8_t* blob, const uint64_t* offsets, size_t n, const 
  * 16 and proves as its Poseidon component (six trace rows per record).  Any mix of shapes; the records of a proof
  * that is rejected behind the parser are whatever its (failing) verification computed.  With d_flow the per-query
  * kernels walk every path to the root themselves (no shared top-of-tree cap, no shared row hashes), like the circuit.
- * PINNED by the reference only through the count (the padded flow of level K's verification is level K+1's Poseidon
- * trace, whose log size is in that fixture's header: tests/test_oracle.py); the values are checked against this
- * repo's restatement of the per-path verifiers and against perm(inputs) = outputs.  The wire indices of
- * PoseidonEntry / SwapOption::addr are circuit bookkeeping and are not produced. */
+ * PINNED value by value through the fixture chain: the circuit that verifies fixture K, rebuilt from these records and the
+ * witness below, evaluated at fixture K+1's OODS point, gives K+1's sampled values (tests/test_witness_gpu.py: the GPU's
+ * own flow reproduces the next fixture's 88 Poseidon columns for all 14 pairs; oracle/recursion_circuit).  The wire
+ * indices of PoseidonEntry / SwapOption::addr are constants of the shape: rsv_witness_program_export (flow_wires). */
 #define RSV_TRANSCRIPT_WORDS 284
 typedef struct {
     uint32_t n_queries, max_log, n_inner; /* declared common shape; ignored when no path output is requested */
@@ -499,7 +499,10 @@ void rsv_witness_program_destroy(rsv_witness_program* prog);
  * order Rust seeds per process (components/recursive/answer/src/lib.rs:44-71), so the reference's own circuit comes in
  * four variants per copy that differ in the ORDER of two pairs of blocks of variables (the values are the same); bit 0 =
  * the Plonk set is walked -1 first, bit 1 = the Poseidon set.  A prover that already fixed its gate list (preprocessed
- * columns) passes the walks that list was made with. */
+ * columns) passes the walks that list was made with.  A PROVER INTEGRATION MUST DO SO: the library cannot observe which of
+ * the four orders a given run of the reference took (the tests recover them per fixture pair by trying the four against the
+ * next fixture's sampled values, tests/pin_recursion_circuit.py); with the wrong walks every value is still right but two
+ * pairs of blocks of `variables` sit in the other order than the prover's wires expect. */
 int rsv_witness_program_build(const uint8_t* proof, size_t len, const rsv_pcs_config* cfg, const rsv_public_input* pi, size_t n_pi,
                               uint32_t copies, const uint8_t* set_walks, int device, rsv_witness_program** out);
 /* Sizes, then the arrays (any pointer may be NULL): instr [n_vars][8], level_offsets [n_levels + 1], flow_wires

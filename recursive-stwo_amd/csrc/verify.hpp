@@ -4,12 +4,12 @@
 // Stage            kernel (file)                      parallelism                  reference
 // ---------------  ---------------------------------  ---------------------------  ----------------------------------------
 // wire format      k_parse (k_parse.hpp)              1 lane / proof               bincode of PlonkWithPoseidonProof
-// canonicity       k_scan (k_parse.hpp)               1 wave / proof, 16 B/lane    (M31 words must be < P)
+// canonicity       (in the kernel that reads a word)  —                            M31 words must be < P: layout.hpp; fallback in k_finalize
 // transcript       k_transcript[_row] (k_transcript)  1 lane or 1 DPP row / proof  components/recursive/fiat_shamir/src/lib.rs:31-176
 // OODS identity    k_oods (k_oods.hpp)                1 lane / proof               components/recursive/composition/src/**
 // decommit plan    k_plan_par (k_plan.hpp)            1 lane / (proof, query)      components/hints/src/decommit.rs:53-142, folding.rs:107-212
 // quotient consts  k_qconst (k_plan.hpp)              1 lane / proof               components/recursive/answer/src/data_structures.rs:132-189
-// quotients+folds  k_query (k_query.hpp)              1 lane / (proof, query)      components/recursive/answer/src/**, folding/src/lib.rs:57-204
+// quotients+folds  k_query<QB> (k_query.hpp)          1 lane / (proof, query)      components/recursive/answer/src/**, folding/src/lib.rs:57-204
 // column hashing   k_row_hash (k_merkle.hpp)          1 lane / (proof, tree, row)  primitives/merkle/src/lib.rs:50-181
 // trace trees      k_trace_merkle (k_merkle.hpp)      1 lane / (proof,tree,query)  components/recursive/data_structures/src/lib.rs:315-354
 // FRI trees        k_pair_merkle (k_merkle.hpp)       1 lane / (proof,layer,query) components/recursive/data_structures/src/lib.rs:400-464

@@ -84,3 +84,18 @@ def test_bench_two_ranks_rehearsal():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _check_line(out.stdout, 2)
     assert d["config"]["parallelism"] == "shard2"
+
+
+def test_committed_profile_holds_the_large_batch_line():
+    """VERDICT r3 #6 — hold, don't dig: the committed profile of the default workload (profiles/pmc_latest.json, written by
+    tools/profile.sh + tools/pmc_summary.py from a gpurun of `python bench.py` on one MI355X) must show >= 1.90 M proofs/s
+    and <= 2.6 x the algorithmic bytes in HBM traffic over the pipeline; a change that costs the large batch more than
+    that does not get committed with a fresh profile."""
+    with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+        prof = json.load(f)
+    if "pipeline_traffic_ratio" not in prof:
+        pytest.skip("profile written before round 4")
+    assert prof["proofs"] == 65536 and prof["bench_value_proofs_per_s"] >= 1.90e6, prof["bench_value_proofs_per_s"]
+    assert prof["pipeline_traffic_ratio"] <= 2.6, prof["pipeline_traffic_ratio"]
+    dom = prof["kernels"]["k_pair_merkle"]
+    assert dom["avg_ms"] < 23.0 and dom["SQ_INSTS_VALU"] > 1e10

@@ -85,6 +85,16 @@ def main():
                 continue  # a FLOW / side instantiation of a template kernel never replaces the verdict instantiation
             latest["kernels"][short] = {"avg_ms": ms, "hbm_bytes_corrected": int((2 * fetch + write) * 1024),
                                         "SQ_INSTS_VALU": int(c.get("SQ_INSTS_VALU", 0)), "eff_clock_GHz": round(clock, 3)}
+    # traffic of one step: every pipeline kernel once (k_cap_top runs twice per step: its trace-tree launch moves about as much
+    # as the FRI one counted here, 0.1 GB), against the algorithmic bytes of the bench line
+    bench = json.load(open(os.path.join(src, "bench_n1_65536.json")))
+    algo = int(bench["roofline"]["algorithmic_bytes_per_launch"])
+    pipe = sum(v["hbm_bytes_corrected"] for k, v in latest["kernels"].items() if k not in ("k_permute", "k_emulated", "k_half_permute"))
+    latest["algorithmic_bytes"] = algo
+    latest["pipeline_hbm_bytes"] = pipe
+    latest["pipeline_traffic_ratio"] = round(pipe / algo, 3)
+    latest["bench_value_proofs_per_s"] = bench["value"]
+    latest["bench_ms_per_step"] = bench["ms_per_step"]
     with open(os.path.join(dst, "pmc_latest.json"), "w") as f:
         json.dump(latest, f, indent=1)
     print("wrote profiles/" + tag + "_*")
