@@ -170,6 +170,8 @@ typedef enum rsv_option {
                                      of every query through it written from there, 2 every lane hashes its whole path itself */
     RSV_OPT_PAIR_ORDER = 22,      /* 0 / 1 a k_pair_merkle launch that is resident all at once deals its FRI trees (grid rows) out over the
                                      compute units by depth (the dispatcher does not balance such a launch), 2 grid row y = tree y */
+    RSV_OPT_TREE_PACE = 23,       /* 0 auto (small batches: 2), 1 the Merkle kernels call the permutation instance with wait states behind
+                                     its multiplies (pays with several waves per SIMD), 2 the one without (a wave nearly alone) */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -31,6 +31,7 @@ struct RowHashArgs {
     ProofCtx* ctxs;        // flags: a non-canonical queried value -> RSV_R_PARSE
 };
 
+template <bool PACE = true>
 __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     RSV_TAG(2);
     RSV_FUSED_SELECT(f, a, bx);
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     uint32_t* out = a.rowh + (((size_t)slot * 4 + t) * 2) * G * 8;
     uint32_t over = 0;  // a non-canonical queried value (this kernel is where queried_values are read: layout.hpp)
     if ((r + 1) * nc_leaf <= qv_n)
-        store_hash(out + (size_t)r * 8, leaf_from_capacity(sponge_capacity_chk(qv + r * nc_leaf, nc_leaf, over)));
+        store_hash(out + (size_t)r * 8, leaf_from_capacity<PACE>(sponge_capacity_chk<PACE>(qv + r * nc_leaf, nc_leaf, over)));
     if (nc_lower && (r + 1) * nc_lower <= qv_n)
-        store_hash(out + ((size_t)G + r) * 8, sponge_capacity_chk(qv + qv_n - (r + 1) * nc_lower, nc_lower, over));
+        store_hash(out + ((size_t)G + r) * 8, sponge_capacity_chk<PACE>(qv + qv_n - (r + 1) * nc_lower, nc_lower, over));
     {
         // The words no row covers: empty for every list the Merkle stage accepts (its rows tile the list: nd_leaf <= nq
         // leaf rows from the start, nd_lower <= nq lower rows from the end); a longer or ragged list is rejected there,
@@ -125,7 +126,7 @@ struct CapGroup {
 // of every query whose path passes through it (the records differ only in which child is "self": swap = the position's
 // parity).  fl[0][lane] = record index of that query's step from level Lc (0xFFFFFFFF: none), fl[1][lane] = its position
 // at level Lc; the query lanes of group g are threads g * G .. g * G + G - 1.
-template <int BLOCK, bool FLOW = false>
+template <int BLOCK, bool FLOW = false, bool PACE = true>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
                                            const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0, uint32_t Lt = 0,
@@ -197,7 +198,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
                             else flow_put(fs, idx0 + (Lc - 1u - l), left, right, st, 0u);
                         }
                     }
-                } else node = hash_tree(left, right);
+                } else node = hash_tree<PACE>(left, right);
                 if (l == 0) {
                     if (bad || !hash_eq(node, load_hash(d.root))) atomicOr(d.flags, (1u << d.fail_bit) | (bad ? F_RESCAN : 0u));
                 } else {
@@ -228,7 +229,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 // writes the PoseidonFlow records of ITS path — leaf sponge, one swap-permute per level, the lower column level's
 // sponge and combine — at the index the circuit's invocation order gives them (layout.hpp).  The circuit hashes every
 // query's leaf and column rows itself, so in this mode the lane does too (k_row_hash hashes each distinct row once).
-template <int BLOCK, bool FLOW = false>
+template <int BLOCK, bool FLOW = false, bool PACE = true>
 __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(3);
     RSV_FUSED_SELECT(f, a, bx);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
                 fidx = fbase + flow_chunks(nc_leaf) + 1u + (mx - lvl) + extra;
                 cur = rate_of(flow_perm(fs, fidx + (nc ? flow_chunks(nc) : 0u), cur, sib, odd));
             } else
-            cur = hash_tree_swap(cur, sib, odd);
+            cur = hash_tree_swap<PACE>(cur, sib, odd);
             if (nc) {
                 // lower-level rows were hashed counting from the end of queried_values
                 const uint32_t nd_lower = lvl_nd(h->lvl[pl_]), row = ent_rb(ent[pl_ * G + j]);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
                         const Hash8 colcap = flow_sponge_capacity(fs, fidx, w + m->qv_off[t] + off, nc);
                         cur = rate_of(flow_perm(fs, fidx + flow_chunks(nc) + 1u, cur, colcap, false));
                     } else
-                    cur = combine_with_column(cur, load_hash(rows + ((size_t)G + (nd_lower - 1 - row)) * 8));
+                    cur = combine_with_column<PACE>(cur, load_hash(rows + ((size_t)G + (nd_lower - 1 - row)) * 8));
                     if (a.path_cols) {
                         uint32_t* pc = a.path_cols + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * 64 + nc_leaf;
                         const uint32_t* src = w + m->qv_off[t] + off;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
             capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + flow_chunks(nc_leaf) + 1u + (mx - Lc) + extra : 0xFFFFFFFFu;
             capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
         }
-        merkle_cap<BLOCK, FLOW>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
+        merkle_cap<BLOCK, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
                                 a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t, capfl, G);
     }
 }
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
 // first-layer tree, the two column capacities and the two combines — the sibling node's combine is then computed by
 // the lane itself from the sibling's children hash (another lane's, through xch2, or hashed from the witness pair,
 // which the circuit takes as a hint and does not hash).
-template <int BLOCK, bool FLOW = false>
+template <int BLOCK, bool FLOW = false, bool PACE = true>
 __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(4);
     RSV_FUSED_SELECT(f, a, bx);
@@ -457,8 +458,8 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
             cur = rate_of(flow_perm(fs, fbase + 1u, zero8(), flow_capacity4(fs, fbase, lv), false));
             sibh = rate_of(flow_perm(fs, fbase + 3u, zero8(), flow_capacity4(fs, fbase + 2u, lv + 4), false));
         } else {
-        cur = leaf_from_capacity(sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
-        sibh = leaf_from_capacity(sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+        cur = leaf_from_capacity<PACE>(sponge_capacity4<PACE>(lv[0], lv[1], lv[2], lv[3]));
+        sibh = leaf_from_capacity<PACE>(sponge_capacity4<PACE>(lv[4], lv[5], lv[6], lv[7]));
         }
         have_sib = true;
         dslot = 0;
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
             fidx = fbase + 4u + (top - lvl) + 4u * dslot;
             if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + (dg >= 0 ? 2u : 0u), cur, sibh, odd));
             else
-            cur = hash_tree_swap(cur, sibh, odd);
+            cur = hash_tree_swap<PACE>(cur, sibh, odd);
             have_sib = false;
         }
         // phase B: data level of the first-layer tree: fold in the column and build the sibling node
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
             if (a.pair_sib || FLOW) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
             if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + 3u, cur, flow_capacity4(fs, fidx, lv), false));
             else
-            cur = combine_with_column(cur, sponge_capacity4(lv[0], lv[1], lv[2], lv[3]));
+            cur = combine_with_column<PACE>(cur, sponge_capacity4<PACE>(lv[0], lv[1], lv[2], lv[3]));
             store_hash(xcol[threadIdx.x], cur);
         }
         if (exA) buf ^= 1u;
@@ -569,11 +570,11 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
             } else if (w_sib + 1 < L->hash_n) {
                 const Hash8 wl = load_hash(w + L->hash_off + 8 * w_sib), wr = load_hash(w + L->hash_off + 8 * (w_sib + 1));
                 if (hash_over(wl) | hash_over(wr)) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);
-                Hash8 sn = hash_tree(wl, wr);
+                Hash8 sn = hash_tree<PACE>(wl, wr);
                 if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, sn);
                 if (FLOW && fs.rec) sibh = rate_of(flow_perm(fs, fidx + 4u, sn, flow_capacity4(fs, fidx + 1u, lv + 4), false));
                 else
-                sibh = combine_with_column(sn, sponge_capacity4(lv[4], lv[5], lv[6], lv[7]));
+                sibh = combine_with_column<PACE>(sn, sponge_capacity4<PACE>(lv[4], lv[5], lv[6], lv[7]));
             } else bad = true;
             have_sib = true;
             dslot++;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
             capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + 4u + (top - Lc) + 4u * dslot : 0xFFFFFFFFu;
             capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
         }
-        merkle_cap<BLOCK, FLOW>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
+        merkle_cap<BLOCK, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
                                 a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot, capfl, G);
     }
 }
@@ -609,7 +610,7 @@ struct CapTopIndex {
 static_assert(sizeof(Fused<MerkleArgs>) + sizeof(CapTopIndex) + 8 <= 4096 && sizeof(Fused<MerkleArgs>) + sizeof(FlowArgs) <= 4096,
               "kernel arguments are limited to 4 KB");
 
-template <int LT>
+template <int LT, bool PACE = true>
 __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_, uint32_t ti, bool pair) {
     const uint32_t T = pair ? 1u + a.maxInner : 4u;
     const size_t idx = (size_t)slot_ * T + ti;
@@ -658,7 +659,7 @@ __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_
                     if (!(pres & 1u)) left = w8;
                     if (!(pres & 2u)) right = w8;
                 }
-                node[pp] = hash_tree(left, right);
+                node[pp] = hash_tree<PACE>(left, right);
                 if (l == 0) {
                     if (bad || !hash_eq(node[0], load_hash(root))) atomicOr(flags, (1u << fail_bit) | (bad ? F_RESCAN : 0u));
                 } else if (bad) atomicOr(flags, (1u << fail_bit) | F_RESCAN);
@@ -669,6 +670,7 @@ __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_
     }
 }
 
+template <bool PACE = true>
 __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
     RSV_TAG(pair ? 4 : 3);
     uint32_t k = 0;
@@ -678,8 +680,8 @@ __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopInde
     const uint64_t item = (uint64_t)(blockIdx.x - ix.first_block[k]) * 256 + threadIdx.x;
     if (!a.Lt || item >= (uint64_t)a.n * T) return;
     const uint32_t slot_ = (uint32_t)(item / T), ti = (uint32_t)(item % T);
-    if (a.Lt == 2) cap_top_walk<2>(a, slot_, ti, pair != 0);
-    else cap_top_walk<3>(a, slot_, ti, pair != 0);
+    if (a.Lt == 2) cap_top_walk<2, PACE>(a, slot_, ti, pair != 0);
+    else cap_top_walk<3, PACE>(a, slot_, ti, pair != 0);
 }
 
 }  // namespace rsv

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
     } else if (m.reason != R_OK) return;
     ProofCtx& c = ctxs[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
-    Channel ch;
+    Channel<false> ch;  // one wave per SIMD at 65 536 proofs: the unpaced permutation (poseidon2.hpp)
     ch.init();
     if (FLOW) {
         const uint32_t total = flow_total(m.nq, m.n_inner, m.last_n, m.A, m.B, m.M);

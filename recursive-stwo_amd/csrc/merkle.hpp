@@ -18,20 +18,24 @@ __device__ __forceinline__ uint32_t hash_over(const Hash8& h) {
     return o;
 }
 
+// PACE (every helper below): which out-of-line permutation instance it calls (poseidon2.hpp) — the paced one for launches
+// that put several waves on a SIMD, the unpaced one for a small batch, where a wave is nearly alone.
 // hash_m31_columns_get_capacity (primitives/merkle/src/lib.rs:141-181):
 // d = 0; for each zero-padded chunk of 8 words: d = perm(chunk || d)[8..16].
 // `cols` may be any address space; words are read with plain 4-byte loads.
+template <bool PACE = true>
 __device__ inline Hash8 sponge_capacity(const uint32_t* cols, uint32_t n) {
     Hash8 d = zero8();
     for (uint32_t off = 0; off < n; off += 8) {
         Hash8 chunk;
 #pragma unroll
         for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
-        d = perm_cap(chunk, d);
+        d = perm_cap<PACE>(chunk, d);
     }
     return d;
 }
 // the same, reporting a non-canonical column word through `over`
+template <bool PACE = true>
 __device__ inline Hash8 sponge_capacity_chk(const uint32_t* cols, uint32_t n, uint32_t& over) {
     Hash8 d = zero8();
     for (uint32_t off = 0; off < n; off += 8) {
@@ -39,23 +43,27 @@ __device__ inline Hash8 sponge_capacity_chk(const uint32_t* cols, uint32_t n, ui
 #pragma unroll
         for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
         over |= hash_over(chunk);
-        d = perm_cap(chunk, d);
+        d = perm_cap<PACE>(chunk, d);
     }
     return d;
 }
 // The 4-word (one QM31) column of the FRI trees: hash_qm31_columns_get_capacity of
 // [v, 0] (components/recursive/data_structures/src/lib.rs:408-419).
+template <bool PACE = true>
 __device__ inline Hash8 sponge_capacity4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
     Hash8 chunk = zero8();
     chunk.w[0] = v0; chunk.w[1] = v1; chunk.w[2] = v2; chunk.w[3] = v3;
-    return perm_cap(chunk, zero8());
+    return perm_cap<PACE>(chunk, zero8());
 }
 // leaf: hash_m31_columns_get_rate (primitives/merkle/src/lib.rs:50-91)
-__device__ inline Hash8 leaf_from_capacity(const Hash8& d) { return perm_rate(zero8(), d); }
+template <bool PACE = true>
+__device__ inline Hash8 leaf_from_capacity(const Hash8& d) { return perm_rate<PACE>(zero8(), d); }
 // hash_tree (primitives/merkle/src/lib.rs:9-11)
-__device__ inline Hash8 hash_tree(const Hash8& l, const Hash8& r) { return perm_rate(l, r); }
+template <bool PACE = true>
+__device__ inline Hash8 hash_tree(const Hash8& l, const Hash8& r) { return perm_rate<PACE>(l, r); }
 // hash_tree_with_swap (primitives/merkle/src/lib.rs:22-30): ONE call site for both orders — a lane-divergent
 // `odd ? hash_tree(b, a) : hash_tree(a, b)` would run the permutation twice per wave with half the lanes masked.
+template <bool PACE = true>
 __device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, bool self_is_right) {
     State16 st;
 #pragma unroll
@@ -63,16 +71,18 @@ __device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, 
         st.s[i] = self_is_right ? sibling.w[i] : self.w[i];
         st.s[8 + i] = self_is_right ? self.w[i] : sibling.w[i];
     }
-    return poseidon2_half(st, 0u);
+    return poseidon2_half<PACE>(st, 0u);
 }
 // combine_hash_tree_with_column (primitives/merkle/src/lib.rs:43-48)
-__device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate(tree, col_cap); }
+template <bool PACE = true>
+__device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate<PACE>(tree, col_cap); }
 
 // stwo Poseidon31MerkleHasher::hash_node
+template <bool PACE = true>
 __device__ inline Hash8 hash_node(const Hash8* l, const Hash8* r, const uint32_t* cols, uint32_t n_cols) {
-    if (!l) return leaf_from_capacity(sponge_capacity(cols, n_cols));
-    Hash8 h = hash_tree(*l, *r);
-    if (n_cols) h = combine_with_column(h, sponge_capacity(cols, n_cols));
+    if (!l) return leaf_from_capacity<PACE>(sponge_capacity<PACE>(cols, n_cols));
+    Hash8 h = hash_tree<PACE>(*l, *r);
+    if (n_cols) h = combine_with_column<PACE>(h, sponge_capacity<PACE>(cols, n_cols));
     return h;
 }
 
@@ -134,7 +144,8 @@ __device__ inline Hash8 flow_capacity4(const FlowSink& f, uint32_t idx, const ui
     return cap_of(flow_perm(f, idx, chunk, zero8(), false));
 }
 
-// ChannelVar (primitives/channel/src/lib.rs:24-58)
+// ChannelVar (primitives/channel/src/lib.rs:24-58).  PACE: the permutation instance its operations call (poseidon2.hpp)
+template <bool PACE = true>
 struct Channel {
     Hash8 digest;
     uint32_t n_sent;
@@ -143,7 +154,7 @@ struct Channel {
     __device__ void init() { digest = zero8(); n_sent = 0; flow.rec = nullptr; flow.swap = nullptr; flow_idx = 0; }
     __device__ void mix(const Hash8& left) {
         if (flow.rec) digest = cap_of(flow_perm(flow, flow_idx++, left, digest, false));
-        else digest = perm_cap(left, digest);
+        else digest = perm_cap<PACE>(left, digest);
         n_sent = 0;
     }
     __device__ void mix_two(QM31 f, QM31 g) {
@@ -158,7 +169,7 @@ struct Channel {
         Hash8 l = zero8();
         l.w[0] = n_sent++;
         if (flow.rec) return rate_of(flow_perm(flow, flow_idx++, l, digest, false));
-        return perm_rate(l, digest);
+        return perm_rate<PACE>(l, digest);
     }
 };
 __device__ __forceinline__ QM31 q_lo(const Hash8& h) { return q_mk(h.w[0], h.w[1], h.w[2], h.w[3]); }

@@ -132,235 +132,228 @@ __device__ __forceinline__ void poseidon2_ref_inline(uint32_t* s) {
 //     two wait states behind the multiplies: 36.17 (worse) | s_nop 3: 40.2
 // The wait states cost nothing at >= 4 waves per SIMD (other waves fill them); at one wave per SIMD (the lane-form
 // transcript of batches > 24 576) they lengthen the chain by ~25 % — that kernel runs underneath k_row_hash.
-#ifndef RSV_PACE_MAD
-#define RSV_PACE_MAD "\n\ts_nop 0"
-#endif
-#ifndef RSV_PACE_DBL
-#define RSV_PACE_DBL ""
-#endif
-#ifndef RSV_PACE_CANON
-#define RSV_PACE_CANON 1
-#endif
-#ifndef RSV_PACE_FOLD
-#define RSV_PACE_FOLD 0
-#endif
-__device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {
-    uint64_t d;
-    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-template <int SH>
-__device__ __forceinline__ uint64_t shl_add64(uint64_t a, uint64_t b) {  // (a << SH) + b, SH in 1..4
-    uint64_t d;
-    asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH));
-    return d;
-}
-// 32x32 -> 64 products and multiply-accumulates (v_mad_u64_u32).  The small constant multipliers are
-// passed as OPAQUE wave-uniform values (see opaque()): with a visible constant hipcc strength-reduces
-// a*2+c into slow-class shifts plus zero-extension moves instead of one v_mad_u64_u32.
-__device__ __forceinline__ uint32_t opaque(uint32_t k) {
-    uint32_t r;
-    asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "n"(k));
-    return r;
-}
-// The asm form (instead of `(uint64_t)a * b + c`) also keeps hipcc from re-associating
-// x0*k + x1*k into (x0 + x1)*k, which costs a 64-bit add, a 64x32 multiply and zero-extension moves.
-__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) {
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b_uniform, int) {  // b in an SGPR
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
-    return d;
-}
-__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b_uniform, uint64_t c) {  // a * b + c, b in an SGPR
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" RSV_PACE_MAD : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
-    return d;
-}
-__device__ __forceinline__ uint32_t dbl32(uint32_t x) {  // x + x as a fast-class add (not a shift)
-    uint32_t d;
-    asm("v_add_u32 %0, %1, %1" RSV_PACE_DBL : "=v"(d) : "v"(x));
-    return d;
-}
-// V = 2v with v < 2^62  ->  (v >> 31) + (v & P)
-__device__ __forceinline__ uint32_t fold2(uint64_t V) {
-    uint32_t r = (uint32_t)(V >> 32) + ((uint32_t)V >> 1);
-#if RSV_PACE_FOLD
-    asm volatile("s_nop 0" : "+v"(r));
-#endif
-    return r;
-}
-// t in [0, 2P] -> C
-__device__ __forceinline__ uint32_t canon(uint32_t t) {
-    uint32_t r = min(t, t - P);
-#if RSV_PACE_CANON
-    asm volatile("s_nop 0" : "+v"(r));
-#endif
-    return r;
-}
-
-// x in C  ->  x^5 in L2
-__device__ __forceinline__ uint32_t pow5(uint32_t x) {
-    const uint32_t xx = dbl32(x);                         // 2x <= 2P, used by the first and the last product
-    uint32_t c2 = canon(fold2(mul64(xx, x)));             // 2x^2 < 2^63; fold <= 2P-1
-    uint32_t c4 = canon(fold2(mul64(dbl32(c2), c2)));
-    return fold2(mul64(xx, c4));                          // 2x*c4: hi <= P, lo>>1 <= P
-}
-
-// Y = 2*M4*(x0..x3) for 32-bit inputs (any u32), exact in 64 bits.
-__device__ __forceinline__ void mds4_2x(uint32_t k2, uint32_t k4, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
-                                        uint64_t& y0, uint64_t& y1, uint64_t& y2, uint64_t& y3) {
-    uint64_t T0 = mad64(x0, k2, mul64(x1, k2, 0));           // 2(x0 + x1)
-    uint64_t T1 = mad64(x2, k2, mul64(x3, k2, 0));           // 2(x2 + x3)
-    uint64_t T2 = mad64(x1, k4, T1);                      // 2(2x1 + t1)
-    uint64_t T3 = mad64(x3, k4, T0);                      // 2(2x3 + t0)
-    uint64_t T4 = shl_add64<2>(T1, T3);                   // 2(4t1 + t3)
-    uint64_t T5 = shl_add64<2>(T0, T2);                   // 2(4t0 + t2)
-    y0 = add64(T3, T5);
-    y1 = T5;
-    y2 = add64(T2, T4);
-    y3 = T4;
-}
-
-// V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i], inputs any u32 (< 2^32): the matrix rows sum to at most 16 * 5 = 80, so
-// every V[i] < 2 * 80 * 2^32 < 2^40.  V never carries a round constant (they are literals of the fused reductions).
-__device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, const uint32_t* s, uint64_t* V) {
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-        mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
-#pragma unroll
-        for (int g = 0; g < 4; g++) V[4 * g + j] = add64(V[4 * g + j], sum);
+// PACE: the wait states above (one behind every v_mad_u64_u32, one behind the v_min that ends a reduction).  They pay where
+// several waves share a SIMD and cost ~25 % where a wave is (nearly) alone on it, so the verify kernels pick the instance by
+// the size of the launch (poseidon2_half below): paced for launches that fill the machine, unpaced for a small batch's trees
+// and for the one-wave-per-SIMD lane-form transcript.
+template <bool PACE>
+struct PermT {
+    static __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {
+        uint64_t d;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
     }
-}
-
-// Round constant + canonicalisation in one step.  t = fold2(V) with V the doubled accumulator of a linear layer
-// WITHOUT its round constant: t <= P + HI where HI bounds the accumulator's high word (160 after a full-round
-// layer, < 2^19 after a partial-round one).  With c = P - rc (a compile-time literal):
-//     t >= c :  t - c in [0, P - 1]  (needs c > HI; every constant of this parameter set is < P - 2^19, asserted below)
-//               and t - c + P in [P, 2P - 1]: the minimum is t - c  = t + rc - P
-//     t <  c :  t - c wraps to >= 2^32 - P > 2^31 and t - c + P = t + rc in [0, P - 1]: the minimum is t + rc
-// so min(t - c, t - c + P) is the CANONICAL t + rc mod P in two literal adds (fast class, 2.5 cycles each) and a
-// v_min — against v_mad_u64_u32 (2 * rc folded into V, 5.1) + a literal add + v_min for the unfused form.
-template <uint32_t RC>
-__device__ __forceinline__ uint32_t canon_rc(uint32_t t) {
-    static_assert(RC < P - (1u << 19), "round constant too close to P for the fused reduction");
-    constexpr uint32_t c = P - RC;
-    uint32_t r = min(t - c, t + (P - c));
-#if RSV_PACE_CANON
-    asm volatile("s_nop 0" : "+v"(r));
-#endif
-    return r;
-}
-
-template <int R, int I>
-__device__ __forceinline__ void sbox_full(const uint64_t* V, uint32_t* s) {
-    s[I] = pow5(canon_rc<RC_FULL_K[R][I]>(fold2(V[I])));
-    if constexpr (I + 1 < 16) sbox_full<R, I + 1>(V, s);
-}
-// the first full round of the second half takes its inputs already folded (from the last partial round)
-template <int I>
-__device__ __forceinline__ void sbox_full4(uint32_t* s) {
-    s[I] = pow5(canon_rc<RC_FULL_K[4][I]>(s[I]));
-    if constexpr (I + 1 < 16) sbox_full4<I + 1>(s);
-}
-
-template <int R>
-__device__ __forceinline__ void partial_round(uint32_t* s, uint32_t k2, uint32_t k6, const uint32_t* kd) {
-    uint32_t u0 = pow5(canon_rc<RC_PARTIAL_K[R]>(s[0]));                 // s[0] <= P + 2^19
-    // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
-    uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
-#pragma unroll
-    for (int i = 2; i < 16; i += 2) { a = mad64(s[i], k2, a); b = mad64(s[i + 1], k2, b); }
-    uint64_t sum2 = add64(a, b);
-    // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50, so every fold is <= P + 2^18
-    s[0] = fold2(mad64(u0, k6, sum2));
-#pragma unroll
-    for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
-}
-
-// Everything up to and including the S-box layer of the last full round: s = that layer's outputs (range L2).
-__device__ __forceinline__ void poseidon2_rounds(uint32_t* s, uint32_t k2, uint32_t k4) {
-    uint64_t V[16];
-    const uint32_t k6 = opaque(6);
-    // s: canonical input.  V never carries a round constant: the constants are literals of the fused reductions.
-    mds16_2x(k2, k4, s, V);
-    sbox_full<0, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<1, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<2, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<3, 0>(V, s); mds16_2x(k2, k4, s, V);
-    // partial rounds: every lane lazily folded (<= P + 2^18), lane 0 goes through the S-box
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
-    // 2 * diag: 2^(i+2) for lanes 1..15, as opaque wave-uniform multipliers
-    uint32_t kd[16];
-    kd[0] = k6;
-#define RSV_KD(i) kd[i] = opaque(4u << (i));
-    RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
-    RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
-#undef RSV_KD
-    partial_round<0>(s, k2, k6, kd);  partial_round<1>(s, k2, k6, kd);  partial_round<2>(s, k2, k6, kd);
-    partial_round<3>(s, k2, k6, kd);  partial_round<4>(s, k2, k6, kd);  partial_round<5>(s, k2, k6, kd);
-    partial_round<6>(s, k2, k6, kd);  partial_round<7>(s, k2, k6, kd);  partial_round<8>(s, k2, k6, kd);
-    partial_round<9>(s, k2, k6, kd);  partial_round<10>(s, k2, k6, kd); partial_round<11>(s, k2, k6, kd);
-    partial_round<12>(s, k2, k6, kd); partial_round<13>(s, k2, k6, kd);
-    sbox_full4<0>(s);      mds16_2x(k2, k4, s, V);
-    sbox_full<5, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<6, 0>(V, s); mds16_2x(k2, k4, s, V);
-    sbox_full<7, 0>(V, s);
-}
-
-__device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
-    const uint32_t k2 = opaque(2), k4 = opaque(4);
-    poseidon2_rounds(s, k2, k4);
-    uint64_t V[16];
-    mds16_2x(k2, k4, s, V);
-    // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        uint32_t t = fold2(V[i]);
-        s[i] = min(t, t - P);
+    template <int SH>
+    static __device__ __forceinline__ uint64_t shl_add64(uint64_t a, uint64_t b) {  // (a << SH) + b, SH in 1..4
+        uint64_t d;
+        asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(d) : "v"(a), "v"(b), "n"(SH));
+        return d;
     }
-}
+    // 32x32 -> 64 products and multiply-accumulates (v_mad_u64_u32).  The small constant multipliers are
+    // passed as OPAQUE wave-uniform values (see opaque()): with a visible constant hipcc strength-reduces
+    // a*2+c into slow-class shifts plus zero-extension moves instead of one v_mad_u64_u32.
+    static __device__ __forceinline__ uint32_t opaque(uint32_t k) {
+        uint32_t r;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "n"(k));
+        return r;
+    }
+    // The asm form (instead of `(uint64_t)a * b + c`) also keeps hipcc from re-associating
+    // x0*k + x1*k into (x0 + x1)*k, which costs a 64-bit add, a 64x32 multiply and zero-extension moves.
+    static __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) {
+        uint64_t d, carry;
+        if constexpr (PACE) asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\ts_nop 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+        else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+        return d;
+    }
+    static __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b_uniform, int) {  // b in an SGPR
+        uint64_t d, carry;
+        if constexpr (PACE) asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\ts_nop 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
+        else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
+        return d;
+    }
+    static __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b_uniform, uint64_t c) {  // a * b + c, b in an SGPR
+        uint64_t d, carry;
+        if constexpr (PACE) asm("v_mad_u64_u32 %0, %1, %2, %3, %4\n\ts_nop 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+        else asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+        return d;
+    }
+    static __device__ __forceinline__ uint32_t dbl32(uint32_t x) {  // x + x as a fast-class add (not a shift)
+        uint32_t d;
+        asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
+        return d;
+    }
+    // V = 2v with v < 2^62  ->  (v >> 31) + (v & P)
+    static __device__ __forceinline__ uint32_t fold2(uint64_t V) {
+        uint32_t r = (uint32_t)(V >> 32) + ((uint32_t)V >> 1);
+        return r;
+    }
+    // t in [0, 2P] -> C
+    static __device__ __forceinline__ uint32_t canon(uint32_t t) {
+        uint32_t r = min(t, t - P);
+        if constexpr (PACE) asm volatile("s_nop 0" : "+v"(r));
+        return r;
+    }
 
-// The last linear layer for ONE half of the state (hi = 0: words 0..7, the rate; 1: words 8..15, the capacity): the four
-// M4 blocks and the column sums are needed either way, the per-word additions, folds and canonicalisations only for
-// the eight words asked for — every hash of the verify pipeline keeps one half of the permutation's output
-// (Poseidon2HalfVar::permute's ignore_left_result / ignore_right_result, primitives/poseidon31/src/lib.rs:251-288).
-template <bool HI_CONST = false, bool HI_VALUE = false>
-__device__ __forceinline__ void poseidon2_inline_half(uint32_t* s, uint32_t hi, uint32_t* out8) {
-    if (HI_CONST) hi = HI_VALUE ? 1u : 0u;
-    const uint32_t k2 = opaque(2), k4 = opaque(4);
-    poseidon2_rounds(s, k2, k4);
-    uint64_t V[16];
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-        mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
-    // one column at a time (the column sum lives in two registers), the branch outside the loop: the instance must fit
-    // the 40 caller-saved registers v0..v39 like poseidon2(), or the Merkle kernels spill around every call
-    if (hi) {  // wave-uniform at every call site
-#pragma unroll
+    // x in C  ->  x^5 in L2
+    static __device__ __forceinline__ uint32_t pow5(uint32_t x) {
+        const uint32_t xx = dbl32(x);                         // 2x <= 2P, used by the first and the last product
+        uint32_t c2 = canon(fold2(mul64(xx, x)));             // 2x^2 < 2^63; fold <= 2P-1
+        uint32_t c4 = canon(fold2(mul64(dbl32(c2), c2)));
+        return fold2(mul64(xx, c4));                          // 2x*c4: hi <= P, lo>>1 <= P
+    }
+
+    // Y = 2*M4*(x0..x3) for 32-bit inputs (any u32), exact in 64 bits.
+    static __device__ __forceinline__ void mds4_2x(uint32_t k2, uint32_t k4, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                            uint64_t& y0, uint64_t& y1, uint64_t& y2, uint64_t& y3) {
+        uint64_t T0 = mad64(x0, k2, mul64(x1, k2, 0));           // 2(x0 + x1)
+        uint64_t T1 = mad64(x2, k2, mul64(x3, k2, 0));           // 2(x2 + x3)
+        uint64_t T2 = mad64(x1, k4, T1);                      // 2(2x1 + t1)
+        uint64_t T3 = mad64(x3, k4, T0);                      // 2(2x3 + t0)
+        uint64_t T4 = shl_add64<2>(T1, T3);                   // 2(4t1 + t3)
+        uint64_t T5 = shl_add64<2>(T0, T2);                   // 2(4t0 + t2)
+        y0 = add64(T3, T5);
+        y1 = T5;
+        y2 = add64(T2, T4);
+        y3 = T4;
+    }
+
+    // V[i] = 2 * (circ(2M4, M4, M4, M4) * s)[i], inputs any u32 (< 2^32): the matrix rows sum to at most 16 * 5 = 80, so
+    // every V[i] < 2 * 80 * 2^32 < 2^40.  V never carries a round constant (they are literals of the fused reductions).
+    static __device__ __forceinline__ void mds16_2x(uint32_t k2, uint32_t k4, const uint32_t* s, uint64_t* V) {
+    #pragma unroll
+        for (int g = 0; g < 4; g++)
+            mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
+    #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
-            const uint32_t t0 = fold2(add64(V[8 + j], sum)), t1 = fold2(add64(V[12 + j], sum));
-            out8[j] = min(t0, t0 - P);
-            out8[4 + j] = min(t1, t1 - P);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
-            const uint32_t t0 = fold2(add64(V[j], sum)), t1 = fold2(add64(V[4 + j], sum));
-            out8[j] = min(t0, t0 - P);
-            out8[4 + j] = min(t1, t1 - P);
+            uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+    #pragma unroll
+            for (int g = 0; g < 4; g++) V[4 * g + j] = add64(V[4 * g + j], sum);
         }
     }
-}
+
+    // Round constant + canonicalisation in one step.  t = fold2(V) with V the doubled accumulator of a linear layer
+    // WITHOUT its round constant: t <= P + HI where HI bounds the accumulator's high word (160 after a full-round
+    // layer, < 2^19 after a partial-round one).  With c = P - rc (a compile-time literal):
+    //     t >= c :  t - c in [0, P - 1]  (needs c > HI; every constant of this parameter set is < P - 2^19, asserted below)
+    //               and t - c + P in [P, 2P - 1]: the minimum is t - c  = t + rc - P
+    //     t <  c :  t - c wraps to >= 2^32 - P > 2^31 and t - c + P = t + rc in [0, P - 1]: the minimum is t + rc
+    // so min(t - c, t - c + P) is the CANONICAL t + rc mod P in two literal adds (fast class, 2.5 cycles each) and a
+    // v_min — against v_mad_u64_u32 (2 * rc folded into V, 5.1) + a literal add + v_min for the unfused form.
+    template <uint32_t RC>
+    static __device__ __forceinline__ uint32_t canon_rc(uint32_t t) {
+        static_assert(RC < P - (1u << 19), "round constant too close to P for the fused reduction");
+        constexpr uint32_t c = P - RC;
+        uint32_t r = min(t - c, t + (P - c));
+        if constexpr (PACE) asm volatile("s_nop 0" : "+v"(r));
+        return r;
+    }
+
+    template <int R, int I>
+    static __device__ __forceinline__ void sbox_full(const uint64_t* V, uint32_t* s) {
+        s[I] = pow5(canon_rc<RC_FULL_K[R][I]>(fold2(V[I])));
+        if constexpr (I + 1 < 16) sbox_full<R, I + 1>(V, s);
+    }
+    // the first full round of the second half takes its inputs already folded (from the last partial round)
+    template <int I>
+    static __device__ __forceinline__ void sbox_full4(uint32_t* s) {
+        s[I] = pow5(canon_rc<RC_FULL_K[4][I]>(s[I]));
+        if constexpr (I + 1 < 16) sbox_full4<I + 1>(s);
+    }
+
+    template <int R>
+    static __device__ __forceinline__ void partial_round(uint32_t* s, uint32_t k2, uint32_t k6, const uint32_t* kd) {
+        uint32_t u0 = pow5(canon_rc<RC_PARTIAL_K[R]>(s[0]));                 // s[0] <= P + 2^19
+        // sum2 = 2 * (u0 + s[1] + ... + s[15]) < 2^37, two chains
+        uint64_t a = mul64(u0, k2, 0), b = mul64(s[1], k2, 0);
+    #pragma unroll
+        for (int i = 2; i < 16; i += 2) { a = mad64(s[i], k2, a); b = mad64(s[i + 1], k2, b); }
+        uint64_t sum2 = add64(a, b);
+        // 2 * (d_i * s_i + sum), d = (3, 4, 8, ..., 65536): < 2^50, so every fold is <= P + 2^18
+        s[0] = fold2(mad64(u0, k6, sum2));
+    #pragma unroll
+        for (int i = 1; i < 16; i++) s[i] = fold2(mad64(s[i], kd[i], sum2));
+    }
+
+    // Everything up to and including the S-box layer of the last full round: s = that layer's outputs (range L2).
+    static __device__ __forceinline__ void poseidon2_rounds(uint32_t* s, uint32_t k2, uint32_t k4) {
+        uint64_t V[16];
+        const uint32_t k6 = opaque(6);
+        // s: canonical input.  V never carries a round constant: the constants are literals of the fused reductions.
+        mds16_2x(k2, k4, s, V);
+        sbox_full<0, 0>(V, s); mds16_2x(k2, k4, s, V);
+        sbox_full<1, 0>(V, s); mds16_2x(k2, k4, s, V);
+        sbox_full<2, 0>(V, s); mds16_2x(k2, k4, s, V);
+        sbox_full<3, 0>(V, s); mds16_2x(k2, k4, s, V);
+        // partial rounds: every lane lazily folded (<= P + 2^18), lane 0 goes through the S-box
+    #pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = fold2(V[i]);
+        // 2 * diag: 2^(i+2) for lanes 1..15, as opaque wave-uniform multipliers
+        uint32_t kd[16];
+        kd[0] = k6;
+    #define RSV_KD(i) kd[i] = opaque(4u << (i));
+        RSV_KD(1) RSV_KD(2) RSV_KD(3) RSV_KD(4) RSV_KD(5) RSV_KD(6) RSV_KD(7) RSV_KD(8)
+        RSV_KD(9) RSV_KD(10) RSV_KD(11) RSV_KD(12) RSV_KD(13) RSV_KD(14) RSV_KD(15)
+    #undef RSV_KD
+        partial_round<0>(s, k2, k6, kd);  partial_round<1>(s, k2, k6, kd);  partial_round<2>(s, k2, k6, kd);
+        partial_round<3>(s, k2, k6, kd);  partial_round<4>(s, k2, k6, kd);  partial_round<5>(s, k2, k6, kd);
+        partial_round<6>(s, k2, k6, kd);  partial_round<7>(s, k2, k6, kd);  partial_round<8>(s, k2, k6, kd);
+        partial_round<9>(s, k2, k6, kd);  partial_round<10>(s, k2, k6, kd); partial_round<11>(s, k2, k6, kd);
+        partial_round<12>(s, k2, k6, kd); partial_round<13>(s, k2, k6, kd);
+        sbox_full4<0>(s);      mds16_2x(k2, k4, s, V);
+        sbox_full<5, 0>(V, s); mds16_2x(k2, k4, s, V);
+        sbox_full<6, 0>(V, s); mds16_2x(k2, k4, s, V);
+        sbox_full<7, 0>(V, s);
+    }
+
+    static __device__ __forceinline__ void poseidon2_inline(uint32_t* s) {
+        const uint32_t k2 = opaque(2), k4 = opaque(4);
+        poseidon2_rounds(s, k2, k4);
+        uint64_t V[16];
+        mds16_2x(k2, k4, s, V);
+        // canonical output: fold <= P + 160, so one conditional subtract lands in [0, P); P itself maps to 0
+    #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t t = fold2(V[i]);
+            s[i] = min(t, t - P);
+        }
+    }
+
+    // The last linear layer for ONE half of the state (hi = 0: words 0..7, the rate; 1: words 8..15, the capacity): the four
+    // M4 blocks and the column sums are needed either way, the per-word additions, folds and canonicalisations only for
+    // the eight words asked for — every hash of the verify pipeline keeps one half of the permutation's output
+    // (Poseidon2HalfVar::permute's ignore_left_result / ignore_right_result, primitives/poseidon31/src/lib.rs:251-288).
+    template <bool HI_CONST = false, bool HI_VALUE = false>
+    static __device__ __forceinline__ void poseidon2_inline_half(uint32_t* s, uint32_t hi, uint32_t* out8) {
+        if (HI_CONST) hi = HI_VALUE ? 1u : 0u;
+        const uint32_t k2 = opaque(2), k4 = opaque(4);
+        poseidon2_rounds(s, k2, k4);
+        uint64_t V[16];
+    #pragma unroll
+        for (int g = 0; g < 4; g++)
+            mds4_2x(k2, k4, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], V[4 * g], V[4 * g + 1], V[4 * g + 2], V[4 * g + 3]);
+        // one column at a time (the column sum lives in two registers), the branch outside the loop: the instance must fit
+        // the 40 caller-saved registers v0..v39 like poseidon2(), or the Merkle kernels spill around every call
+        if (hi) {  // wave-uniform at every call site
+    #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+                const uint32_t t0 = fold2(add64(V[8 + j], sum)), t1 = fold2(add64(V[12 + j], sum));
+                out8[j] = min(t0, t0 - P);
+                out8[4 + j] = min(t1, t1 - P);
+            }
+        } else {
+    #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t sum = add64(add64(V[j], V[j + 4]), add64(V[j + 8], V[j + 12]));
+                const uint32_t t0 = fold2(add64(V[j], sum)), t1 = fold2(add64(V[4 + j], sum));
+                out8[j] = min(t0, t0 - P);
+                out8[4 + j] = min(t1, t1 - P);
+            }
+        }
+    }
+};
+// (tools/perm_lab.hip, k_permute: the paced form)
+__device__ __forceinline__ void poseidon2_inline(uint32_t* s) { PermT<true>::poseidon2_inline(s); }
 
 #ifdef RSV_COUNT_PERMS
 // Diagnostic build only (make count): executed permutations per kernel tag — [2t] active lanes, [2t+1] wave-level calls.
@@ -419,7 +412,12 @@ __device__ __forceinline__ Hash8 zero8() {
 #define RSV_HALF_INSTANCES 2   // 1: one out-of-line instance with a run-time half selector (51 VGPRs: the Merkle kernels spill 32 B per lane around the calls); 2: one instance per half (39 VGPRs each, no spill).  Same step time (35.06-35.14 vs 35.10-35.16 ms); 2 moves 1 GB less
 #endif
 #if RSV_HALF_INSTANCES == 2
-template <bool HI>
+// One out-of-line instance per output half and pacing.  The Merkle kernels (several waves per SIMD wherever a launch
+// fills the machine) call the PACED ones; the lane-form transcript — one wave per SIMD for 65 536 proofs — the unpaced
+// ones (k_transcript: 3.21 -> 2.66 ms).  A choice per call site by launch size (tried: small batches' trees unpaced, one
+// proof 1.31 -> 1.22 ms) doubles every call in the Merkle kernels, which then spill 80-112 bytes per lane around them and
+// lose 4.7 % at 65 536 proofs: not taken; the choice is the call site's own template argument.
+template <bool HI, bool PACE>
 __device__ __noinline__ Hash8 poseidon2_half_t(State16 st) {
 #ifdef RSV_COUNT_PERMS
     {
@@ -431,11 +429,12 @@ __device__ __noinline__ Hash8 poseidon2_half_t(State16 st) {
     }
 #endif
     Hash8 h;
-    poseidon2_inline_half<true, HI>(st.s, 0u, h.w);
+    PermT<PACE>::template poseidon2_inline_half<true, HI>(st.s, 0u, h.w);
     return h;
 }
+template <bool PACE = true>
 __device__ __forceinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {  // hi is a literal at every call site
-    return hi ? poseidon2_half_t<true>(st) : poseidon2_half_t<false>(st);
+    return hi ? poseidon2_half_t<true, PACE>(st) : poseidon2_half_t<false, PACE>(st);
 }
 #else
 // Out-of-line instance shared by every hash of the verify kernels: one half of the output (hi = 0 rate, 1 capacity).
@@ -451,12 +450,14 @@ __device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
 #endif
     Hash8 h;
     // hi is a constant of the call site, the same on every active lane: held in an SGPR, not in a 41st VGPR
-    poseidon2_inline_half(st.s, (uint32_t)__builtin_amdgcn_readfirstlane((int)hi), h.w);
+    PermT<true>::poseidon2_inline_half(st.s, (uint32_t)__builtin_amdgcn_readfirstlane((int)hi), h.w);
     return h;
 }
 #endif
-__device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 0u); }
-__device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return poseidon2_half(join(l, r), 1u); }
+template <bool PACE = true>
+__device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half<PACE>(join(l, r), 0u); }
+template <bool PACE = true>
+__device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return poseidon2_half<PACE>(join(l, r), 1u); }
 __device__ __forceinline__ bool hash_eq(const Hash8& a, const Hash8& b) {
     uint32_t d = 0;
 #pragma unroll

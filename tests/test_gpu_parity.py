@@ -529,6 +529,31 @@ def test_cap_disabled_matches_cap_enabled(rsv, knobs):
     assert a2.tolist() == wa.tolist() and r2.tolist() == wr.tolist()
 
 
+@pytest.mark.parametrize("pace", ["paced", "unpaced"])
+@pytest.mark.parametrize("order", ["on", "off"])
+def test_tree_kernel_forms_match_oracle(rsv, knobs, pace, order):
+    """The Merkle kernels' two permutation instances (with / without wait states; picked by batch size in production) and
+    the two assignments of FRI trees to grid rows (dealt out by depth for a launch that is resident all at once / row y =
+    tree y), forced on one batch of several shapes with tampered copies: verdicts and reasons == the oracle's."""
+    names = ["recursive_proof_16_15.bin", "level1-5.bin", "level12-1.bin", "level9-1.bin", "level3-1.bin"]
+    batch, cfgs = [], []
+    for k in range(70):
+        nm = names[k % len(names)] if k % 7 == 0 else names[0]
+        pr = read_proof(nm)
+        batch.append(ob.tamper(pr, k) if k % 3 == 1 else pr)
+        cfgs.append(fixture_cfg(nm))
+    knobs.set("tree_pace", pace)
+    knobs.set("pair_order", order)
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist() and 20 < int(acc.sum()) < 60
+    # one configuration (the device-side slot order, where the tree order is computed from the configuration alone)
+    one = [b for b, c in zip(batch, cfgs) if c.n_queries == 16 and c.log_blowup_factor == 5][:40]
+    acc1, reason1 = rsv.verify_batch(one, fixture_cfg(names[0]))
+    o1, r1 = ob.verify_batch(one, fixture_cfg(names[0]))
+    assert acc1.tolist() == o1.tolist() and reason1.tolist() == r1.tolist()
+
+
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])
 def test_trace_paths_match_oracle(rsv, manifest, name):
     """per-query authentication paths (transcript order) emitted by the GPU == oracle's."""
