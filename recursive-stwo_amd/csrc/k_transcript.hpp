@@ -10,7 +10,10 @@ namespace rsv {
 // FLOW: also writes the PoseidonFlow records of the channel operations (layout.hpp; rsv_hints_out::d_flow), including
 // the surplus query draws the circuit makes (it draws ceil(n_queries / 4) times where ceil(n_queries / 8) hold every
 // query, fiat_shamir/src/lib.rs:119-130), and decides whether this proof's records fit the caller's stride.
-template <bool FLOW, int PHASE = 0>
+// PACE: the permutation instance of the channel (poseidon2.hpp): unpaced while the launch leaves a wave alone on its SIMD
+// (up to 49 152 proofs: 32 768 proofs 17.6 -> 17.3 ms), paced beyond (131 072 proofs are two waves per SIMD: 68.4 against
+// 69.3 ms unpaced; 65 536: 34.25 against 34.3-34.5).
+template <bool FLOW, int PHASE = 0, bool PACE = true>
 __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                    uint32_t n, const ProofMeta* __restrict__ metas,
                                                    ProofCtx* __restrict__ ctxs, FlowArgs fa) {
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(64) void k_transcript(const uint8_t* __restrict__ b
     } else if (m.reason != R_OK) return;
     ProofCtx& c = ctxs[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
-    Channel<false> ch;  // one wave per SIMD at 65 536 proofs: the unpaced permutation (poseidon2.hpp)
+    Channel<PACE> ch;
     ch.init();
     if (FLOW) {
         const uint32_t total = flow_total(m.nq, m.n_inner, m.last_n, m.A, m.B, m.M);
