@@ -9,8 +9,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# --witness-proofs 0: the side leg re-runs the pipeline's kernels on a small batch, and the summaries take each kernel's LAST dispatch
-BENCH_ARGS="--steps 2 --warmup 1 --cpu-sample 0 --perm-log2 20 --witness-proofs 0"
+# --witness-proofs 0 --no-single-proof: the side legs re-run the pipeline's kernels on a small batch, and the summaries take each kernel's LAST dispatch
+BENCH_ARGS="--steps 2 --warmup 1 --cpu-sample 0 --perm-log2 20 --witness-proofs 0 --no-single-proof"
 timeout -k 10 400 python3 bench.py > "$OUT/bench_n1_65536.json" 2> "$OUT/bench.err"
 echo "bench done"
 cd /tmp
@@ -20,7 +20,7 @@ python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.k
 # four separate --pmc passes (TCC: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ: 8 slots; GRBM on its own)
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     NAME=$(echo $C | cut -d' ' -f1)
-    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$NAME" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --perm-log2 20 --witness-proofs 0 > "$OUT/pmc_$NAME.json" 2> "$OUT/pmc_$NAME.err"
+    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$NAME" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --perm-log2 20 --witness-proofs 0 --no-single-proof > "$OUT/pmc_$NAME.json" 2> "$OUT/pmc_$NAME.err"
     echo "pmc $NAME done"
 done
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete   # keep the merge under gpurun's 64 MiB limit
