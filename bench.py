@@ -248,6 +248,13 @@ def main():
                          "critical_chain=off.  The bench line is measured with none.")
     ap.add_argument("--witness-proofs", type=int, default=1024,
                     help="side leg: the recursion circuit's witness for this many proofs of the level10 shape (0 = skip; skipped with --perm-log2 0)")
+    ap.add_argument("--no-stage-times", dest="stage_times", action="store_false",
+                    help="do not record the per-stage HIP events (RSV_OPT_STAGE_TIMES): what a production caller runs; the event "
+                         "pairs cost ~8 us per stage, which matters for batches of a few thousand proofs and below (tools/sweep.sh "
+                         "measures latency this way).  roofline.kernel_ms / stage_ms are then null.")
+    ap.add_argument("--lib", default=None,
+                    help="A/B only: another build of the library than csrc/librsv_hip.so (same ABI), e.g. one built from the "
+                         "previous commit's kernel sources, measured on the same box")
     ap.add_argument("--rehearsal", action="store_true",
                     help="one-GPU box only: every rank on cuda:0, bitmap exchange over gloo (RCCL refuses two ranks on one "
                          "device).  The driver's runs never pass it: they use one GPU per rank and nccl (= RCCL).")
@@ -268,7 +275,7 @@ def main():
         sys.exit(launcher.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import rsvload
-    rsv = rsvload.load_package()
+    rsv = rsvload.load_package(args.lib)
     from recursive_stwo_amd import sharding
     import torch
     import torch.distributed as dist
@@ -296,6 +303,12 @@ def main():
     d_blob, d_offsets, plen, tam, fix_idx = build_batch_on_device(torch, dev, n, first, fixtures)
     total_bytes = int(plen.sum())
     sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch)
+    if args.stage_times:  # the roofline's kernel time comes from HIP events on the verifier's streams
+        try:
+            sv.ctx.set_option("stage_times", "on")
+        except Exception:
+            if not args.lib:  # (an older build under --lib has the clock always on)
+                raise
     # the configuration of every proof: the reference's literal for the fixture it was copied from
     fcfg = fixture_configs(rsv, fixtures)
     cfg = sv.ctx.prepare_cfg([fcfg[k] for k in fix_idx], n) if len({rsv._cfg_key(c) for c in fcfg}) > 1 else rsv.PreparedCfg([fcfg[0]])
@@ -356,7 +369,7 @@ def main():
     for _ in range(args.steps):
         step()
         # HIP-event stage times of this step (reads events already recorded on the verifier's streams)
-        if rank == 0:
+        if rank == 0 and args.stage_times:
             for k, v in sv.ctx.last_stage_times().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     fence()
@@ -408,8 +421,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.inflight * args.steps / dt
     stage_avg = {k: v / args.steps for k, v in stage_sum.items()}
-    dom = max((k for k in stage_avg if k.endswith("merkle")), key=lambda k: stage_avg[k])
-    dom_ms = stage_avg[dom]
+    if stage_avg:
+        dom = max((k for k in stage_avg if k.endswith("merkle")), key=lambda k: stage_avg[k])
+        dom_ms = stage_avg[dom]
+    else:  # --no-stage-times: no kernel time, so achieved / frac / valu_issue_frac are not computed (0 / null)
+        dom, dom_ms = "pair_merkle", 0.0
     algo_bytes = total_bytes + n  # proof bytes read once + 1 accept byte per proof
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC bytes measured by tools/profile.sh on THESE kernel sources, else null.
@@ -440,9 +456,9 @@ def main():
     # 8 TB/s), as SURVEY 8d defines them; valu_issue_frac is the binding one.
     roofline = {"bound": "valu", "nominal_bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue_frac": valu_issue_frac,
-                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms if stage_avg else None,
                 "pipeline_ms": ms_per_step, "pipeline_GBps": pipeline_gbps, "pipeline_frac": pipeline_gbps / HBM_PEAK_GBPS,
-                "stage_ms": stage_avg,
+                "stage_ms": stage_avg or None,
                 "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY §8d); see valu. "
                         "frac charges the whole proof to the dominant kernel (SURVEY §8d's numerator); pipeline_frac "
                         "is the same bytes over the wall time of a step on rank 0.  valu_issue_frac = SQ_INSTS_VALU of the "
@@ -461,6 +477,8 @@ def main():
         d_so = torch.tensor([0, len(sp)], dtype=torch.int64, device=dev)
         d_sa = torch.zeros(1, dtype=torch.uint8, device=dev)
         scfg = rsv.PreparedCfg([fcfg[0]])
+        if not args.lib:
+            ctx.set_option("stage_times", "off")  # as a caller runs it: the stage clock is a diagnostic (~8 us per stage)
         lat = []
         for k in range(35):
             torch.cuda.synchronize()

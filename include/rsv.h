@@ -172,6 +172,8 @@ typedef enum rsv_option {
                                      compute units by depth (the dispatcher does not balance such a launch), 2 grid row y = tree y */
     RSV_OPT_TREE_PACE = 23,       /* 0 auto (small batches: 2), 1 the Merkle kernels call the permutation instance with wait states behind
                                      its multiplies (pays with several waves per SIMD), 2 the one without (a wave nearly alone) */
+    RSV_OPT_STAGE_TIMES = 24,     /* 0 / 2 off; 1 record a HIP event pair around every stage of a verify call, which is what
+                                     rsv_last_stage_times reads.  Off by default: the records cost ~8 us of queue time per stage */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;
@@ -616,7 +618,8 @@ int rsv_exchange_run(rsv_exchange* x, const uint32_t* d_local, uint32_t* d_gathe
 int rsv_exchange_assemble(size_t n_total, size_t world, const uint32_t* gathered, uint8_t* accept, uint32_t* bitmap);
 
 /* Per-stage kernel time of the last rsv_verify_batch_dev on this ctx, measured
- * with HIP events on the ctx stream (ms).  names[i] are static strings.
+ * with HIP events on the ctx stream (ms); all zero unless RSV_OPT_STAGE_TIMES = 1 was set
+ * on the context before the call.  names[i] are static strings.
  * Returns the number of stages written (<= cap).  Synchronises the stream. */
 int rsv_last_stage_times(rsv_ctx* ctx, const char** names, float* ms, int cap);
 

@@ -44,17 +44,32 @@ __device__ inline QM31 fold_pair(QM31 self, QM31 sib, bool odd, uint32_t inv_coo
 // fold(v, [f, rest]) = fold(v_lo, rest) + f * fold(v_hi, rest), i.e. sum_i coeff_i * prod_k d[k]^(bit (log_n-1-k) of i).
 // The weights factor into a table over the low 4 index bits (registers) times a product over the high bits.
 // cf: n = 2^log_n QM31 coefficients (4 words each).
-__device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x) {
-    uint32_t d[16];
-    for (uint32_t k = 0; k < 16; k++) { d[k] = (k < log_n) ? x : 1u; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+// No array here is indexed at run time: the factors are brought into index-bit order by a 4-stage barrel shift of
+// registers.  (A run-time index put d[] in scratch memory, and a kernel that uses scratch costs ~15 us more per launch on
+// this part — tools/chain_lab.hip — which a small batch pays in full: k_query is on its chain of dependent kernels.)
+__device__ __forceinline__ QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x) {
+    // r[15 - j] = pi^j(x); index bit b of a coefficient pairs with pi^(log_n-1-b)(x) = r[b + 16 - log_n]
+    uint32_t r[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { r[15 - j] = x; x = m_sub(m_dbl(m_sqr(x)), 1u); }
+    const uint32_t s = (16u - log_n) & 15u;  // log_n = 0: no factor is read
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1) {
+        const bool on = (s & (uint32_t)st) != 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const uint32_t from = t + st < 16 ? r[t + st] : 1u;
+            r[t] = on ? from : r[t];
+        }
+    }
+    // now r[b] is the factor of index bit b (b < log_n)
     const uint32_t nlo = log_n < 4 ? log_n : 4u;
     uint32_t wl[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) wl[t] = 1u;
-    // low index bit b pairs with d[log_n - 1 - b]
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-        uint32_t db = (uint32_t)b < nlo ? d[(log_n - 1 - b) & 15u] : 1u;
+        const uint32_t db = (uint32_t)b < nlo ? r[b] : 1u;
 #pragma unroll
         for (int t = 0; t < 16; t++)
             if (t & (1 << b)) wl[t] = m_mul(wl[t], db);
@@ -63,13 +78,19 @@ __device__ inline QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n
     const uint32_t n_hi = n >> nlo, n_lo = 1u << nlo;
 #pragma unroll 1
     for (uint32_t hi = 0; hi < n_hi; hi++) {
+        // hi > 0 only when log_n > 4, i.e. nlo = 4: bit b of hi is index bit b + 4
         uint32_t wh = 1u;
-        for (uint32_t b = 0; b + nlo < log_n; b++)
-            if ((hi >> b) & 1u) wh = m_mul(wh, d[(log_n - 1 - nlo - b) & 15u]);
+#pragma unroll
+        for (int b = 0; b < 12; b++)
+            if ((uint32_t)b + 4u < log_n && ((hi >> b) & 1u)) wh = m_mul(wh, r[b + 4]);
         QM31 inner = q_zero();
 #pragma unroll
-        for (int t = 0; t < 16; t++)
+        for (int t = 0; t < 16; t++) {
             if ((uint32_t)t < n_lo) inner = q_add(inner, q_mul_m(ldq(cf + 4 * ((hi << nlo) + t)), wl[t]));
+            // four coefficients in flight, not sixteen: the scheduler would otherwise hoist all 64 words of loads and
+            // the caller (k_query) would lose a wave per SIMD to this function's registers
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         acc = q_add(acc, q_mul_m(inner, wh));
     }
     return acc;
@@ -85,6 +106,12 @@ __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q
 template <int BLOCK, uint32_t QB>
 __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     __shared__ uint32_t xq[BLOCK][4];
+    // each lane's first-layer folds (one QM31 per column size), word-major so that a wave's access is conflict free.  In
+    // LDS, not registers: they are written early and read in the inner-layer loop, and 12 more live registers would cost
+    // the kernel its fifth wave per SIMD.  (Indexed arrays in registers end up in scratch memory, which costs a small
+    // batch ~15 us per launch: tools/chain_lab.hip.)
+    __shared__ uint32_t fst[3][4][BLOCK];
+    __shared__ uint32_t dps[3][2][BLOCK];  // and its domain point at each column size (x, y), for the same reason
     // The FRI trees wait for this kernel while it shares the machine with the trace trees: its waves go first in the
     // SIMDs' arbitration, so that it is over in a fraction of the trace trees' time and the FRI trees start beside them.
     __builtin_amdgcn_s_setprio(3);
@@ -107,17 +134,19 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     uint32_t qj = live ? c->q[j] : 0;
     uint32_t* qv = (live && a.qv_out) ? a.qv_out + ((size_t)slot * G + c->qperm[j]) * a.qv_stride : nullptr;
     uint32_t n_sizes = live ? c->n_sizes : 0;
-    QM31 first[3];
+    auto put_first = [&](uint32_t g, QM31 v) {
+        fst[g][0][threadIdx.x] = v.a.a; fst[g][1][threadIdx.x] = v.a.b; fst[g][2][threadIdx.x] = v.b.a; fst[g][3][threadIdx.x] = v.b.b;
+    };
+    auto get_first = [&](uint32_t g) { return q_mk(fst[g][0][threadIdx.x], fst[g][1][threadIdx.x], fst[g][2][threadIdx.x], fst[g][3][threadIdx.x]); };
     // Domain points.  One scalar multiplication gives the point of the query at level M; the points at the
     // smaller column sizes follow by the doubling map pi(x, y) = (2x^2 - 1, 2xy): doubling the level-l point of
     // position pos gives the level-(l-1) point of pos >> 1 up to the sign of y, which is fixed by bit 0 of the
     // respective positions (CanonicCoset::circle_domain().at(bit_reverse(.))).
-    CPoint dp[3];
     if (live) {
         CPoint cur = domain_point(M, qj);
         uint32_t lvl = M;
-        for (uint32_t g = 0; g < n_sizes; g++) {
-            const uint32_t l = c->sizes[g];
+        auto descend = [&](uint32_t g) {
+            const uint32_t l = g < n_sizes ? c->sizes[g] : lvl;
             while (lvl > l) {
                 const uint32_t pos = qj >> (M - lvl);
                 uint32_t y2 = m_dbl(m_mul(cur.x, cur.y));
@@ -125,14 +154,16 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                 cur.y = ((pos ^ (pos >> 1)) & 1u) ? m_neg(y2) : y2;
                 lvl--;
             }
-            dp[g] = cur;
-        }
+            dps[g][0][threadIdx.x] = cur.x; dps[g][1][threadIdx.x] = cur.y;
+        };
+        descend(0); descend(1); descend(2);
     }
     // ---- DEEP quotients + first-layer fold, per column log size
     for (uint32_t g = 0; g < 3; g++) {
         QM31 answer = q_zero();
         uint32_t l = 0, pos = 0;
         bool on = live && g < n_sizes;
+        uint32_t dpg_y = 0;
         if (on) {
             l = c->sizes[g];
             pos = qj >> (M - l);
@@ -184,13 +215,17 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                     }
                 }
             }
+            const CPoint dpg = {dps[g][0][threadIdx.x], dps[g][1][threadIdx.x]};  // read here, not above: not live over the columns
+            dpg_y = dpg.y;
             for (uint32_t bi = 0; bi < c->n_batches[g]; bi++) {
                 const QBatch& qb = c->batch[g][bi];
                 CM31 prx = c_mk(qb.prx[0], qb.prx[1]), pix = c_mk(qb.pix[0], qb.pix[1]);
                 CM31 pry = c_mk(qb.pry[0], qb.pry[1]), piy = c_mk(qb.piy[0], qb.piy[1]);
-                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dp[g].y), ldq(qb.sb)));
-                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dp[g].x, 0)), piy), c_mul(c_sub(pry, c_mk(dp[g].y, 0)), pix));
-                answer = q_add(answer, q_mul_c(num, c_inv(den)));
+                CM31 den = c_sub(c_mul(c_sub(prx, c_mk(dpg.x, 0)), piy), c_mul(c_sub(pry, c_mk(dpg.y, 0)), pix));
+                const CM31 inv_den = c_inv(den);
+                __builtin_amdgcn_sched_barrier(0);  // the inversion's temporaries are dead before the numerator's loads are issued (96 registers)
+                QM31 num = q_sub(q_mul_c(bi ? r1 : r0, piy), q_add(q_mul_m(ldq(qb.sa), dpg.y), ldq(qb.sb)));
+                answer = q_add(answer, q_mul_c(num, inv_den));
             }
         }
         // exchange answers: the pair sibling may be another query of this proof
@@ -209,10 +244,11 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
             stq(lv, answer); stq(lv + 4, sib);
             // fold circle -> line with 1/y of the pair's base point (folding/src/lib.rs:57-90); the base
             // point (bit 0 of the position cleared) is the conjugate of this point when the position is odd
-            uint32_t by = (pos & 1u) ? m_neg(dp[g].y) : dp[g].y;
-            first[g] = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
-            if (a.folded_out) stq(a.folded_out + (((size_t)slot * 3 + g) * G + c->qperm[j]) * 4, first[g]);
-            if (qv) { stq(qv + 4 * g, answer); stq(qv + 12 + 4 * g, first[g]); }
+            uint32_t by = (pos & 1u) ? m_neg(dpg_y) : dpg_y;
+            const QM31 fg = fold_pair(answer, sib, pos & 1u, m_inv(by), ldq(c->fri_alpha[M - l]));
+            put_first(g, fg);
+            if (a.folded_out) stq(a.folded_out + (((size_t)slot * 3 + g) * G + c->qperm[j]) * 4, fg);
+            if (qv) { stq(qv + 4 * g, answer); stq(qv + 12 + 4 * g, fg); }
         }
         __syncthreads();
     }
@@ -222,14 +258,14 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     // the bit-reversed index by half the coset = the point (-1, 0), i.e. negates x).
     QM31 folded = q_zero();
     uint32_t l = M;
-    uint32_t X = live ? dp[0].x : 0u;
+    uint32_t X = live ? dps[0][0][threadIdx.x] : 0u;  // x of the query's point at the largest column size
     for (uint32_t i = 0; i < a.maxInner; i++) {
         bool on = live && i < m->n_inner;
         if (on) {
             for (uint32_t g = 0; g < n_sizes; g++)
                 if (c->sizes[g] == l) {
                     QM31 al = ldq(c->fri_alpha[i]);
-                    folded = q_add(q_mul(q_mul(al, al), folded), first[g]);
+                    folded = q_add(q_mul(q_mul(al, al), folded), get_first(g));
                 }
             l -= 1;
         }

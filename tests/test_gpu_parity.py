@@ -354,6 +354,8 @@ def test_device_resident_api_and_bitmap(rsv):
     d_bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
     ctx = rsv.Context(0)
+    assert all(v == 0 for v in ctx.last_stage_times().values())   # the stage clock is opt-in
+    ctx.set_option("stage_times", "on")
     for _ in range(2):  # second call reuses the workspace
         ctx.verify_batch(d_blob, d_off, n, d_acc, d_reason, cfg=fixture_cfg("recursive_proof_16_15.bin"))
     ctx.accept_bitmap(d_acc, n, d_bitmap, d_count)

@@ -7,7 +7,7 @@ for K in "$@"; do
   for N in $SIZES; do
     KN=""; [ "$K" != "default" ] && KN="--knob $K"
     ST=$(( 40000 / N + 4 )); [ $ST -gt 40 ] && ST=40
-    timeout -k 10 200 python bench.py --workload copies --proofs $N --steps $ST --warmup 4 --cpu-sample 0 --perm-log2 0 $KN > $OUT/c_${N}_$K.json 2> $OUT/c_${N}_$K.err
+    timeout -k 10 200 python bench.py --workload copies --proofs $N --steps $ST --warmup 4 --cpu-sample 0 --perm-log2 0 --no-stage-times --no-single-proof $KN > $OUT/c_${N}_$K.json 2> $OUT/c_${N}_$K.err
     python - <<PY
 import json
 try:
