@@ -170,8 +170,11 @@ typedef enum rsv_option {
                                      of every query through it written from there, 2 every lane hashes its whole path itself */
     RSV_OPT_PAIR_ORDER = 22,      /* 0 / 1 a k_pair_merkle launch that is resident all at once deals its FRI trees (grid rows) out over the
                                      compute units by depth (the dispatcher does not balance such a launch), 2 grid row y = tree y */
-    RSV_OPT_TREE_PACE = 23,       /* 0 auto (small batches: 2), 1 the Merkle kernels call the permutation instance with wait states behind
-                                     its multiplies (pays with several waves per SIMD), 2 the one without (a wave nearly alone) */
+    RSV_OPT_TREE_PACE = 23,       /* 0 auto (small batches: 2, a few hundred proofs and fewer: 3), 1 the Merkle kernels call the permutation
+                                     instance with wait states behind its multiplies (pays with several waves per SIMD), 2 the one
+                                     without (a wave nearly alone), 3 the row form: 16 threads per Merkle path share every permutation
+                                     (a launch of a few waves: the walk is a chain of dependent permutations, the row form's a
+                                     quarter as long); not with per-query path outputs or more than 32 queries (then: 2) */
     RSV_OPT_STAGE_TIMES = 24,     /* 0 / 2 off; 1 record a HIP event pair around every stage of a verify call, which is what
                                      rsv_last_stage_times reads.  Off by default: the records cost ~8 us of queue time per stage */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a

@@ -31,7 +31,7 @@ struct RowHashArgs {
     ProofCtx* ctxs;        // flags: a non-canonical queried value -> RSV_R_PARSE
 };
 
-template <bool PACE = true>
+template <int PACE = 1>
 __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     RSV_TAG(2);
     RSV_FUSED_SELECT(f, a, bx);
@@ -126,13 +126,14 @@ struct CapGroup {
 // of every query whose path passes through it (the records differ only in which child is "self": swap = the position's
 // parity).  fl[0][lane] = record index of that query's step from level Lc (0xFFFFFFFF: none), fl[1][lane] = its position
 // at level Lc; the query lanes of group g are threads g * G .. g * G + G - 1.
-template <int BLOCK, bool FLOW = false, bool PACE = true>
+// BLOCK: the workgroup's lanes as the kernel indexes them (virtual lanes in the row form)
+template <int BLOCK, bool FLOW = false, int PACE = 1>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
                                            const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0, uint32_t Lt = 0,
                                            uint32_t* capn = nullptr, uint32_t* capm = nullptr, uint32_t slot0 = 0, uint32_t n_slots = 0,
                                            uint32_t T = 0, uint32_t ti = 0, const uint32_t (*fl)[FLOW ? BLOCK : 1] = nullptr, uint32_t G = 0) {
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = vlane<PACE>();
     __syncthreads();  // xch is free, descriptors written
     if (t < per_block) { mask[0][t] = 0; mask[1][t] = 0; }
     __syncthreads();
@@ -229,17 +230,25 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 // writes the PoseidonFlow records of ITS path — leaf sponge, one swap-permute per level, the lower column level's
 // sponge and combine — at the index the circuit's invocation order gives them (layout.hpp).  The circuit hashes every
 // query's leaf and column rows itself, so in this mode the lane does too (k_row_hash hashes each distinct row once).
-template <int BLOCK, bool FLOW = false, bool PACE = true>
-__global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
+// PACE = FORM_ROW (poseidon2.hpp): the same kernel on VIRTUAL lanes — a workgroup of BLOCK threads is BLOCK / 16 lanes of the
+// indexing below, each a DPP row whose 16 threads compute the same indices, load the same words and share every
+// permutation (poseidon2_row_half).  For launches of a few waves (a single proof: 64 paths per tree), where the walk is
+// a chain of dependent permutations and the row form's chain is a quarter as long: one proof's trace trees 285 -> 67 us, its call 1.15 -> 0.82 ms; 128 proofs 1.14 -> 0.91 ms; 512: slower (1.26 -> 1.54).
+// Stores and atomicOr's of the 16 threads coincide (same address, same value).
+template <int BLOCK, bool FLOW = false, int PACE = 1>
+__global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE_WAVES)) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(3);
     RSV_FUSED_SELECT(f, a, bx);
-    __shared__ uint32_t xch[2][BLOCK][8];
+    constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
+    const uint32_t tid = vlane<PACE>();
+    row_rc_init<PACE>();
+    __shared__ uint32_t xch[2][VB][8];
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed;
-    __shared__ uint32_t capfl[2][FLOW ? BLOCK : 1];  // FLOW with a cap: see merkle_cap
-    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
-    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    __shared__ uint32_t capfl[2][FLOW ? VB : 1];  // FLOW with a cap: see merkle_cap
+    const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
+    const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
     const int t = blockIdx.y;
     bool live = grp < per_block && slot_ < a.n;
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
     // has two query paths that are siblings of each other: a level-l node has its sibling on a query path iff the
     // number of distinct nodes grows from level l-1 to l.  Deep in the tree that is rare (16 proofs x 16 queries:
     // ~1 workgroup in 10 at level 14), and a barrier per level makes every wave wait for the slowest of its four.
-    if (threadIdx.x == 0) xneed = 0;
+    if (tid == 0) xneed = 0;
     __syncthreads();
     if (live && j == 0) {
         uint32_t mask = 0;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
         const bool on = live && lvl <= mx;
         const bool exch = (need >> lvl) & 1u;  // workgroup-uniform
         if (exch) {
-            if (on) store_hash(xch[buf][threadIdx.x], cur);
+            if (on) store_hash(xch[buf][tid], cur);
             __syncthreads();
         }
         if (on) {
@@ -388,10 +397,10 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
             // level lies above the cap — the lower column level's chunks + combine
             const uint32_t lower = (live && t != 3 && A != B) ? umin(A, B) : 0u;
             const uint32_t extra = lower ? flow_chunks(lower == A ? plonk_cols(t) : poseidon_cols(t)) + 1u : 0u;
-            capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + flow_chunks(nc_leaf) + 1u + (mx - Lc) + extra : 0xFFFFFFFFu;
-            capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
+            capfl[0][tid] = (live && fs.rec) ? fbase + flow_chunks(nc_leaf) + 1u + (mx - Lc) + extra : 0xFFFFFFFFu;
+            capfl[1][tid] = live ? (qj >> (M - Lc)) : 0u;
         }
-        merkle_cap<BLOCK, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
+        merkle_cap<VB, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
                                 a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t, capfl, G);
     }
 }
@@ -405,12 +414,16 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_TRACE_WAVES) void k_trace_mer
 // first-layer tree, the two column capacities and the two combines — the sibling node's combine is then computed by
 // the lane itself from the sibling's children hash (another lane's, through xch2, or hashed from the witness pair,
 // which the circuit takes as a hint and does not hash).
-template <int BLOCK, bool FLOW = false, bool PACE = true>
-__global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
+// PACE = FORM_ROW: on virtual lanes, as k_trace_merkle (one proof's FRI trees 435 -> 94 us).
+template <int BLOCK, bool FLOW = false, int PACE = 1>
+__global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_WAVES)) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(4);
     RSV_FUSED_SELECT(f, a, bx);
-    __shared__ uint32_t xch[2][BLOCK][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
-    __shared__ uint32_t xcol[BLOCK][8];     // phase B (nodes with their column folded in), data levels only
+    constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
+    const uint32_t tid = vlane<PACE>();
+    row_rc_init<PACE>();
+    __shared__ uint32_t xch[2][VB][8];   // phase A (sibling hashes), toggled per exchange; reused by merkle_cap
+    __shared__ uint32_t xcol[VB][8];     // phase B (nodes with their column folded in), data levels only
     // path emission only: pre-column node hashes at data levels.  Dynamic LDS (BLOCK x 32 bytes, passed by the launch
     // only when pair paths are emitted): without it the kernel holds 29 KB of LDS and five workgroups fit a CU.
     extern __shared__ uint32_t xch2_dyn[];
@@ -418,9 +431,9 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
     __shared__ unsigned long long capmask[2][64];  // per_block <= 64 (the host pads G to >= 4 lanes)
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed[2];
-    __shared__ uint32_t capfl[2][FLOW ? BLOCK : 1];  // FLOW with a cap: see merkle_cap
-    const uint32_t G = a.pl.G, per_block = BLOCK / G, Lc = a.Lc;
-    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    __shared__ uint32_t capfl[2][FLOW ? VB : 1];  // FLOW with a cap: see merkle_cap
+    const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
+    const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
     const uint32_t slot = f.y_of[blockIdx.y];  // which FRI tree this grid row hashes (a permutation chosen by the host for small launches)
     bool live = grp < per_block && slot_ < a.n;
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
     // Workgroup barriers only where lanes really exchange through LDS (see k_trace_merkle): [0] child levels at which
     // some proof of this workgroup has sibling query paths, [1] child levels whose parent carries a column of the
     // first-layer tree.  The column levels also take the phase-A barrier, which orders the reuse of xcol / xch2.
-    if (threadIdx.x < 2) xneed[threadIdx.x] = 0;
+    if (tid < 2) xneed[tid] = 0;
     __syncthreads();
     if (live && j == 0) {
         uint32_t ma = 0, mb = 0;
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
                 if (c->sizes[g] == pl_) dg = (int)g;
         // phase A: sibling hash at the child level
         if (exA) {
-            if (on && !have_sib) store_hash(xch[buf][threadIdx.x], cur);
+            if (on && !have_sib) store_hash(xch[buf][tid], cur);
             __syncthreads();
         }
         if (on) {
@@ -548,11 +561,11 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
         // phase B: data level of the first-layer tree: fold in the column and build the sibling node
         if (on && dg >= 0) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
-            if (a.pair_sib || FLOW) store_hash(xch2[threadIdx.x], cur);  // hash of this node's children, before the column
+            if (a.pair_sib || FLOW) store_hash(xch2[tid], cur);  // hash of this node's children, before the column
             if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + 3u, cur, flow_capacity4(fs, fidx, lv), false));
             else
             cur = combine_with_column<PACE>(cur, sponge_capacity4<PACE>(lv[0], lv[1], lv[2], lv[3]));
-            store_hash(xcol[threadIdx.x], cur);
+            store_hash(xcol[tid], cur);
         }
         if (exA) buf ^= 1u;
         if (exB) __syncthreads();
@@ -589,10 +602,10 @@ __global__ __launch_bounds__(BLOCK, FLOW ? 4 : RSV_PAIR_WAVES) void k_pair_merkl
     if (Lc) {
         if constexpr (FLOW) {
             // this path's record of the step from level Lc: every column level (four extra records each) lies above the cap
-            capfl[0][threadIdx.x] = (live && fs.rec) ? fbase + 4u + (top - Lc) + 4u * dslot : 0xFFFFFFFFu;
-            capfl[1][threadIdx.x] = live ? (qj >> (M - Lc)) : 0u;
+            capfl[0][tid] = (live && fs.rec) ? fbase + 4u + (top - Lc) + 4u * dslot : 0xFFFFFFFFu;
+            capfl[1][tid] = live ? (qj >> (M - Lc)) : 0u;
         }
-        merkle_cap<BLOCK, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
+        merkle_cap<VB, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
                                 a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot, capfl, G);
     }
 }
@@ -610,7 +623,7 @@ struct CapTopIndex {
 static_assert(sizeof(Fused<MerkleArgs>) + sizeof(CapTopIndex) + 8 <= 4096 && sizeof(Fused<MerkleArgs>) + sizeof(FlowArgs) <= 4096,
               "kernel arguments are limited to 4 KB");
 
-template <int LT, bool PACE = true>
+template <int LT, int PACE = 1>
 __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_, uint32_t ti, bool pair) {
     const uint32_t T = pair ? 1u + a.maxInner : 4u;
     const size_t idx = (size_t)slot_ * T + ti;
@@ -670,7 +683,7 @@ __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_
     }
 }
 
-template <bool PACE = true>
+template <int PACE = 1>
 __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
     RSV_TAG(pair ? 4 : 3);
     uint32_t k = 0;

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t hash_over(const Hash8& h) {
 // hash_m31_columns_get_capacity (primitives/merkle/src/lib.rs:141-181):
 // d = 0; for each zero-padded chunk of 8 words: d = perm(chunk || d)[8..16].
 // `cols` may be any address space; words are read with plain 4-byte loads.
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 sponge_capacity(const uint32_t* cols, uint32_t n) {
     Hash8 d = zero8();
     for (uint32_t off = 0; off < n; off += 8) {
@@ -35,7 +35,7 @@ __device__ inline Hash8 sponge_capacity(const uint32_t* cols, uint32_t n) {
     return d;
 }
 // the same, reporting a non-canonical column word through `over`
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 sponge_capacity_chk(const uint32_t* cols, uint32_t n, uint32_t& over) {
     Hash8 d = zero8();
     for (uint32_t off = 0; off < n; off += 8) {
@@ -49,21 +49,21 @@ __device__ inline Hash8 sponge_capacity_chk(const uint32_t* cols, uint32_t n, ui
 }
 // The 4-word (one QM31) column of the FRI trees: hash_qm31_columns_get_capacity of
 // [v, 0] (components/recursive/data_structures/src/lib.rs:408-419).
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 sponge_capacity4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
     Hash8 chunk = zero8();
     chunk.w[0] = v0; chunk.w[1] = v1; chunk.w[2] = v2; chunk.w[3] = v3;
     return perm_cap<PACE>(chunk, zero8());
 }
 // leaf: hash_m31_columns_get_rate (primitives/merkle/src/lib.rs:50-91)
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 leaf_from_capacity(const Hash8& d) { return perm_rate<PACE>(zero8(), d); }
 // hash_tree (primitives/merkle/src/lib.rs:9-11)
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 hash_tree(const Hash8& l, const Hash8& r) { return perm_rate<PACE>(l, r); }
 // hash_tree_with_swap (primitives/merkle/src/lib.rs:22-30): ONE call site for both orders — a lane-divergent
 // `odd ? hash_tree(b, a) : hash_tree(a, b)` would run the permutation twice per wave with half the lanes masked.
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, bool self_is_right) {
     State16 st;
 #pragma unroll
@@ -74,11 +74,11 @@ __device__ inline Hash8 hash_tree_swap(const Hash8& self, const Hash8& sibling, 
     return poseidon2_half<PACE>(st, 0u);
 }
 // combine_hash_tree_with_column (primitives/merkle/src/lib.rs:43-48)
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 combine_with_column(const Hash8& tree, const Hash8& col_cap) { return perm_rate<PACE>(tree, col_cap); }
 
 // stwo Poseidon31MerkleHasher::hash_node
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ inline Hash8 hash_node(const Hash8* l, const Hash8* r, const uint32_t* cols, uint32_t n_cols) {
     if (!l) return leaf_from_capacity<PACE>(sponge_capacity<PACE>(cols, n_cols));
     Hash8 h = hash_tree<PACE>(*l, *r);
@@ -145,7 +145,7 @@ __device__ inline Hash8 flow_capacity4(const FlowSink& f, uint32_t idx, const ui
 }
 
 // ChannelVar (primitives/channel/src/lib.rs:24-58).  PACE: the permutation instance its operations call (poseidon2.hpp)
-template <bool PACE = true>
+template <int PACE = 1>
 struct Channel {
     Hash8 digest;
     uint32_t n_sent;

@@ -432,10 +432,47 @@ __device__ __noinline__ Hash8 poseidon2_half_t(State16 st) {
     PermT<PACE>::template poseidon2_inline_half<true, HI>(st.s, 0u, h.w);
     return h;
 }
-template <bool PACE = true>
-__device__ __forceinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {  // hi is a literal at every call site
-    return hi ? poseidon2_half_t<true, PACE>(st) : poseidon2_half_t<false, PACE>(st);
+// The row form of the same call (poseidon2_row.hpp): the 16 lanes of a DPP row hold the SAME state and the same result,
+// each computes one word of it.  For a launch of a few waves, where a lane-form permutation (one lane, sixteen words) is a
+// chain of ~5 000 instructions and the row form one of ~1 250.
+// Round constants of one lane: RC_FULL[r][i] for the eight full rounds, fetched ONCE per kernel (a load inside the
+// round loop is consumed two instructions later and costs the wave its whole latency, eight times per permutation —
+// more than the arithmetic of the round).  The partial-round constants are literals.
+struct RowRC {
+    uint32_t f[8];
+};
+__device__ __forceinline__ RowRC load_row_rc(uint32_t i) {
+    RowRC k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.f[r] = RC_FULL[r][i];
+    return k;
 }
+template <bool HI>
+__device__ __noinline__ Hash8 poseidon2_row_half(State16 st);
+// The row form's round constants for the out-of-line instance, in LDS: [round][lane of the row].  A kernel that calls
+// poseidon2_half<FORM_ROW> fills the table first (row_rc_init).  Not global memory: a load inside the callee would make it
+// wait for every load its caller has in flight (the memory counter is in order; LDS has a counter of its own) — the tree
+// kernels fetch the next level's sibling while a level is hashed.  Not an argument either: eight more values live across
+// every call, and the callers spill.
+__shared__ uint32_t s_row_rc[8][16];
+template <int PACE>
+__device__ __forceinline__ void row_rc_init() {
+    if constexpr (PACE == 2) {
+        if (threadIdx.x < 128) s_row_rc[threadIdx.x >> 4][threadIdx.x & 15u] = RC_FULL[threadIdx.x >> 4][threadIdx.x & 15u];
+        __syncthreads();
+    }
+}
+// FORM (the `PACE` argument of every helper and kernel below and in merkle.hpp / k_merkle.hpp): 1 the paced lane form,
+// 0 the unpaced lane form, 2 (FORM_ROW) the row form on "virtual lanes" of 16 lanes each.
+constexpr int FORM_ROW = 2;
+template <int PACE = 1>
+__device__ __forceinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {  // hi is a literal at every call site
+    if constexpr (PACE == FORM_ROW) return hi ? poseidon2_row_half<true>(st) : poseidon2_row_half<false>(st);
+    else return hi ? poseidon2_half_t<true, PACE != 0>(st) : poseidon2_half_t<false, PACE != 0>(st);
+}
+// the lane of a kernel's own indexing: a thread (lane forms) or a DPP row of 16 threads that all compute the same (row form)
+template <int PACE>
+__device__ __forceinline__ uint32_t vlane() { return PACE == FORM_ROW ? threadIdx.x >> 4 : threadIdx.x; }
 #else
 // Out-of-line instance shared by every hash of the verify kernels: one half of the output (hi = 0 rate, 1 capacity).
 __device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
@@ -454,9 +491,9 @@ __device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
     return h;
 }
 #endif
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half<PACE>(join(l, r), 0u); }
-template <bool PACE = true>
+template <int PACE = 1>
 __device__ __forceinline__ Hash8 perm_cap(const Hash8& l, const Hash8& r) { return poseidon2_half<PACE>(join(l, r), 1u); }
 __device__ __forceinline__ bool hash_eq(const Hash8& a, const Hash8& b) {
     uint32_t d = 0;

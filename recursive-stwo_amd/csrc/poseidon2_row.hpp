@@ -43,18 +43,7 @@ __device__ __forceinline__ uint32_t sum_row(uint32_t x) {
     return m_add(x, dpp<DPP_ROR8>(x));
 }
 
-// Round constants of one lane: RC_FULL[r][i] for the eight full rounds, fetched ONCE per kernel (a load inside the
-// round loop is consumed two instructions later and costs the wave its whole latency, eight times per permutation —
-// more than the arithmetic of the round).  The partial-round constants are literals.
-struct RowRC {
-    uint32_t f[8];
-};
-__device__ __forceinline__ RowRC load_row_rc(uint32_t i) {
-    RowRC k;
-#pragma unroll
-    for (int r = 0; r < 8; r++) k.f[r] = RC_FULL[r][i];
-    return k;
-}
+// (RowRC / load_row_rc: the lane's round constants, fetched once per kernel — poseidon2.hpp)
 
 // row_newbcast:0 — lane 0 of every row, in all 16 lanes of that row
 constexpr int DPP_BCAST0 = 0x150;
@@ -171,6 +160,56 @@ __device__ __forceinline__ uint32_t poseidon2_row(uint32_t x, uint32_t i, const 
     for (int r = 4; r < 7; r++) x = mds_row_w(sbox_w(x), odd, k.f[r + 1]);
     x = mds_row_w(sbox_w(x), odd, 0u);                                        // <= P + 2^8
     return min(x, x - P);
+}
+
+// row_share:N — lane N of every row, in all 16 lanes of that row
+template <int N>
+__device__ __forceinline__ uint32_t row_share(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_BCAST0 + N, 0xF, 0xF, true);
+}
+
+// lanes whose bit in `lanes` is set take b, the others a
+__device__ __forceinline__ uint32_t lane_select(uint32_t a, uint32_t b, uint64_t lanes) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(lanes));
+    return r;
+}
+
+// poseidon2_half on a "virtual lane" (poseidon2.hpp): every lane of the row passes the same state and receives the same
+// half of the output.  Lane i takes word i of the state (four levels of selects on the bits of i), the row permutes, and
+// the eight output words are read back from the lanes that hold them (row_share).  The callers' control flow is uniform
+// over a row (all 16 lanes carry the same indices), so the row's lanes are active together wherever this is called.
+template <bool HI>
+__device__ __noinline__ Hash8 poseidon2_row_half(State16 st) {
+#ifdef RSV_COUNT_PERMS
+    {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m) / 16ull);
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
+        }
+    }
+#endif
+    const uint32_t i = threadIdx.x & 15u;  // (workgroups are multiples of 64 threads: rows are aligned)
+    RowRC k;                               // issued first: the first constant is needed ~45 instructions on
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.f[r] = s_row_rc[r][i];
+    // (asm: written as ?: the compiler sees sixteen values picked by an index, stores the state to scratch memory and
+    // loads one word back — a memory round trip per permutation and scratch in every kernel that calls this)
+    uint32_t a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = lane_select(st.s[2 * j], st.s[2 * j + 1], 0xAAAAAAAAAAAAAAAAull);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = lane_select(a[2 * j], a[2 * j + 1], 0xCCCCCCCCCCCCCCCCull);
+#pragma unroll
+    for (int j = 0; j < 2; j++) c[j] = lane_select(b[2 * j], b[2 * j + 1], 0xF0F0F0F0F0F0F0F0ull);
+    const uint32_t y = poseidon2_row(lane_select(c[0], c[1], 0xFF00FF00FF00FF00ull), i, k);
+    Hash8 h;
+    h.w[0] = row_share<(HI ? 8 : 0) + 0>(y); h.w[1] = row_share<(HI ? 8 : 0) + 1>(y);
+    h.w[2] = row_share<(HI ? 8 : 0) + 2>(y); h.w[3] = row_share<(HI ? 8 : 0) + 3>(y);
+    h.w[4] = row_share<(HI ? 8 : 0) + 4>(y); h.w[5] = row_share<(HI ? 8 : 0) + 5>(y);
+    h.w[6] = row_share<(HI ? 8 : 0) + 6>(y); h.w[7] = row_share<(HI ? 8 : 0) + 7>(y);
+    return h;
 }
 
 }  // namespace rsv

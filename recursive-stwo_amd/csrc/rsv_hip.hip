@@ -48,7 +48,7 @@ struct Options {
     int witness_layout = 0;    // 0 / 1 d_variables [proof][variable], 2 [variable][proof]
     int flow_cap = 0;          // PoseidonFlow passes: 0 / 1 top-of-tree cap (shared nodes hashed once), 2 every lane walks to the root
     int stage_times = 0;       // 0 / 2 off, 1 record an event pair around every stage (rsv_last_stage_times)
-    int tree_pace = 0;         // 0 auto (by batch size), 1 the tree kernels on the paced permutation instances, 2 on the unpaced ones
+    int tree_pace = 0;         // 0 auto (by batch size), 1 the tree kernels on the paced permutation instances, 2 on the unpaced ones, 3 in the row form (16 threads per path)
     int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
@@ -253,7 +253,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_CAP_TOP: return tri(&o.cap_top);
         case RSV_OPT_FLOW_CAP: return tri(&o.flow_cap);
         case RSV_OPT_PAIR_ORDER: return tri(&o.pair_order);
-        case RSV_OPT_TREE_PACE: return tri(&o.tree_pace);
+        case RSV_OPT_TREE_PACE: if (value < 0 || value > 3) return (int)RSV_E_RANGE; o.tree_pace = (int)value; return (int)RSV_OK;
         case RSV_OPT_STAGE_TIMES: return tri(&o.stage_times);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;

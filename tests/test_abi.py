@@ -72,11 +72,13 @@ def test_options_are_explicit_and_validated(rsv):
     assert lib.rsv_ctx_set_option(None, 999, 1) == -2          # RSV_E_SIZE: unknown option
     assert lib.rsv_ctx_set_option(None, 0, 1) == -2
     for name in ("transcript_form", "transcript_split", "oods_form", "qconst_form", "plan_form", "tree_cap", "overlap_trees",
-                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "tree_pace", "stage_times"):
+                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "stage_times"):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], 3) == -5, name   # RSV_E_RANGE
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], -1) == -5, name
         for v in (2, 1, 0):
             assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], v) == 0, name
+    for v, want in ((4, -5), (-1, -5), (3, 0), (2, 0), (1, 0), (0, 0)):  # four settings: auto, paced, unpaced, row form
+        assert lib.rsv_ctx_set_option(None, rsv.OPTIONS["tree_pace"], v) == want, v
     for name, bad, good in (("ws_budget_mb", 0, 8192), ("perm_wg_per_cu", 9, 8), ("host_chunk_mb", 0, 256), ("host_threads", 65, 0),
                             ("debug_log", 2, 0), ("witness_small_max", (1 << 20) + 2, 0), ("witness_small_log", 8, 0), ("witness_walk_log", 8, 0)):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], bad) == -5, name

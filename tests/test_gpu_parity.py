@@ -531,11 +531,11 @@ def test_cap_disabled_matches_cap_enabled(rsv, knobs):
     assert a2.tolist() == wa.tolist() and r2.tolist() == wr.tolist()
 
 
-@pytest.mark.parametrize("pace", ["paced", "unpaced"])
+@pytest.mark.parametrize("pace", ["paced", "unpaced", "row16"])
 @pytest.mark.parametrize("order", ["on", "off"])
 def test_tree_kernel_forms_match_oracle(rsv, knobs, pace, order):
-    """The Merkle kernels' two permutation instances (with / without wait states; picked by batch size in production) and
-    the two assignments of FRI trees to grid rows (dealt out by depth for a launch that is resident all at once / row y =
+    """The Merkle kernels' three forms (lane form with / without wait states, row form on virtual lanes of 16 threads;
+    picked by batch size in production) and the two assignments of FRI trees to grid rows (dealt out by depth for a launch that is resident all at once / row y =
     tree y), forced on one batch of several shapes with tampered copies: verdicts and reasons == the oracle's."""
     names = ["recursive_proof_16_15.bin", "level1-5.bin", "level12-1.bin", "level9-1.bin", "level3-1.bin"]
     batch, cfgs = [], []
@@ -554,6 +554,19 @@ def test_tree_kernel_forms_match_oracle(rsv, knobs, pace, order):
     acc1, reason1 = rsv.verify_batch(one, fixture_cfg(names[0]))
     o1, r1 = ob.verify_batch(one, fixture_cfg(names[0]))
     assert acc1.tolist() == o1.tolist() and reason1.tolist() == r1.tolist()
+    # several configurations of at most 32 queries each (the row form's limit: the first batch above, which holds an
+    # 80-query shape, falls back to the unpaced lane form under "row16"), tampered copies among them
+    few = ["level2-1.bin", "level8-1.bin", "level12-1.bin", "level10-1.bin", "small_proof.bin", "level6-1.bin"]
+    batch2 = [read_proof(few[k % len(few)]) for k in range(30)]
+    batch2 = [ob.tamper(pr, 3 * k) if k % 4 == 2 else pr for k, pr in enumerate(batch2)]
+    cfgs2 = [fixture_cfg(few[k % len(few)]) for k in range(30)]
+    acc2, reason2 = rsv.verify_batch(batch2, cfgs2)
+    o2, r2 = ob.verify_batch(batch2, cfgs2)
+    assert acc2.tolist() == o2.tolist() and reason2.tolist() == r2.tolist() and 10 < int(acc2.sum()) < 30
+    # and with the last levels of the cap in k_cap_top (production: batches of >= 1 024 proofs), fed by this form's cap
+    knobs.set("cap_top", "on")
+    acc3, reason3 = rsv.verify_batch(one, fixture_cfg(names[0]))
+    assert acc3.tolist() == o1.tolist() and reason3.tolist() == r1.tolist()
 
 
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])

@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last k_parse starts the last step (a split transcript's front half may start a little earlier)
 last_parse = max(i for i, r in enumerate(rows) if "k_parse" in r["Kernel_Name"])
 first = last_parse
-while first > 0 and "k_transcript_row<1>" in rows[first - 1]["Kernel_Name"]:
+while first > 0 and ("k_transcript_row<1" in rows[first - 1]["Kernel_Name"] or "k_transcript<false, 1" in rows[first - 1]["Kernel_Name"]):
     first -= 1
 t0 = int(rows[first]["Start_Timestamp"])
 prev_end = t0
