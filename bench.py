@@ -431,6 +431,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC bytes measured by tools/profile.sh on THESE kernel sources, else null.
     traffic, traffic_note = None, "traffic: no PMC profile of these kernel sources under profiles/ (tools/profile.sh writes pmc_latest.json)"
     valu_issue_frac = None
+    pipeline_valu_issue_frac = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             prof = json.load(f)
@@ -446,6 +447,10 @@ def main():
             # kernel time, against one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz (the nominal rate)
             if pk.get("SQ_INSTS_VALU") and dom_ms > 0:
                 valu_issue_frac = float(pk["SQ_INSTS_VALU"]) / (dom_ms * 1e-3) / (SIMDS * LAB_GHZ * 1e9 / 2.0)
+            # the whole step: every pipeline kernel's VALU instructions over the step's wall time (kernels overlap, so a
+            # single kernel's span also holds the others' instructions; this figure does not depend on the attribution)
+            if prof.get("pipeline_valu_insts"):
+                pipeline_valu_issue_frac = float(prof["pipeline_valu_insts"]) / (dt / args.steps) / (SIMDS * LAB_GHZ * 1e9 / 2.0)
             traffic_note = (f"traffic: HBM bytes of k_{dom} per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                             f"command on these kernel sources ({prof['tag']}), FETCH_SIZE doubled per MI355X_MICROARCH.md")
     except (OSError, KeyError, ValueError):
@@ -456,6 +461,7 @@ def main():
     # 8 TB/s), as SURVEY 8d defines them; valu_issue_frac is the binding one.
     roofline = {"bound": "valu", "nominal_bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue_frac": valu_issue_frac,
+                "pipeline_valu_issue_frac": pipeline_valu_issue_frac,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms if stage_avg else None,
                 "pipeline_ms": ms_per_step, "pipeline_GBps": pipeline_gbps, "pipeline_frac": pipeline_gbps / HBM_PEAK_GBPS,
                 "stage_ms": stage_avg or None,

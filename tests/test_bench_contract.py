@@ -34,6 +34,7 @@ def _check_line(out, n_gpus):
     # what binds the dominant kernel is integer VALU issue; achieved / peak / frac stay the tier's nominal HBM figure
     assert r["bound"] == "valu" and r["nominal_bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["valu_issue_frac"] is None or 0 < r["valu_issue_frac"] <= 1.0
+    assert r["pipeline_valu_issue_frac"] is None or 0 < r["pipeline_valu_issue_frac"] <= 1.0
     assert 0 < r["pipeline_frac"] <= r["frac"] and (r["traffic"] is None or r["traffic"] > 0)
     assert d["value"] > 0 and d["ms_per_step"] > 0
     return d
@@ -98,4 +99,9 @@ def test_committed_profile_holds_the_large_batch_line():
     assert prof["proofs"] == 65536 and prof["bench_value_proofs_per_s"] >= 1.90e6, prof["bench_value_proofs_per_s"]
     assert prof["pipeline_traffic_ratio"] <= 2.6, prof["pipeline_traffic_ratio"]
     dom = prof["kernels"]["k_pair_merkle"]
-    assert dom["avg_ms"] < 23.0 and dom["SQ_INSTS_VALU"] > 1e10
+    # the FRI trees' span: 21-22 ms while k_query ended ~8 ms into the step; ~25 since it ends at ~4.5 ms and the trees start
+    # beside the trace trees that much earlier (same step time: the whole-step figure below is the one that must hold)
+    assert dom["avg_ms"] < 27.0 and dom["SQ_INSTS_VALU"] > 1e10
+    if "pipeline_valu_insts" in prof:
+        frac = prof["pipeline_valu_insts"] / (prof["bench_ms_per_step"] * 1e-3) / (1024 * 2.4e9 / 2.0)
+        assert 0.5 <= frac <= 1.0, frac

@@ -93,6 +93,9 @@ def main():
     latest["algorithmic_bytes"] = algo
     latest["pipeline_hbm_bytes"] = pipe
     latest["pipeline_traffic_ratio"] = round(pipe / algo, 3)
+    # wave-level VALU instructions of one step (the same kernels): what bench.py prices against the step's wall time — a figure
+    # that does not depend on how the overlapping kernels' spans are attributed
+    latest["pipeline_valu_insts"] = sum(v["SQ_INSTS_VALU"] for k, v in latest["kernels"].items() if k not in ("k_permute", "k_emulated", "k_half_permute"))
     latest["bench_value_proofs_per_s"] = bench["value"]
     latest["bench_ms_per_step"] = bench["ms_per_step"]
     with open(os.path.join(dst, "pmc_latest.json"), "w") as f:
