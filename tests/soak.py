@@ -6,7 +6,8 @@ transcript-absorbed sections (commitments, sampled values, FRI layer commitments
 stopped by the proof of work: they reach the logup / composition checks, and — with query positions that no longer
 match the decommitments — the plan, Merkle and FRI kernels.
 single K: additionally verify the first K proofs of the shuffled corpus ONE PER CALL (uniform-batch path, natural slot
-order, the small-batch kernel forms) and in groups of 3 under the smallest workspace budget the library accepts (1 MB).  The
+order, the small-batch kernel forms), in groups of 3 under the smallest workspace budget the library accepts (1 MB), and
+the first 8 K proofs in one-configuration calls of 5..64 proofs (device-side slot order, row form of the tree kernels).  The
 kernel forms can be forced for every call with trailing name=value arguments (names of rsv.OPTIONS, e.g.
 transcript_form=lane oods_form=row plan_form=serial): they become process defaults (rsv_ctx_set_option, ctx = NULL)."""
 import json
@@ -91,6 +92,23 @@ def main():
         rsv.set_default_option("ws_budget_mb", 8192)
         print(f"single: {k} one-proof calls, mismatches {one}; {k // 3} three-proof calls under the minimum workspace budget, mismatches {three}")
         bad += one + three
+        # one configuration per call, 5..64 proofs: the device-side slot order and (up to 32 queries) the row form of the
+        # tree kernels, on the first 8 k proofs of the corpus
+        by_cfg = {}
+        for i in range(min(8 * k, len(batch))):
+            c = cfgs[i]
+            by_cfg.setdefault((c.pow_bits, c.log_blowup_factor, c.log_last_layer_degree_bound, c.n_queries), []).append(i)
+        small = calls = 0
+        for ix in by_cfg.values():
+            at = 0
+            while at < len(ix):
+                take = ix[at:at + int(rng.integers(5, 65))]
+                at += len(take)
+                a, r = rsv.verify_batch([batch[i] for i in take], cfgs[take[0]])
+                small += int((a != oacc[take]).any() or (r != oreason[take]).any())
+                calls += 1
+        print(f"small: {calls} one-configuration calls of 5..64 proofs, mismatches {small}")
+        bad += small
     sys.exit(1 if bad else 0)
 
 
