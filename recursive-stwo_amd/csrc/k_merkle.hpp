@@ -186,7 +186,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
                 }
                 Hash8 node;
                 if constexpr (FLOW) {
-                    const State16 st = poseidon2(join(left, right));
+                    const State16 st = poseidon2_full<PACE>(join(left, right));
                     node = rate_of(st);
                     if (d.frec) {
                         const FlowSink fs{d.frec, d.fswap};
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
         if ((row + 1) * nc_leaf > qv_n) bad = true;
         else {
             if (FLOW && fs.rec) {  // hash_m31_columns_get_rate (merkle/src/lib.rs:50-91): the chunks, then the rate permutation
-                const Hash8 d = flow_sponge_capacity(fs, fbase, w + m->qv_off[t] + row * nc_leaf, nc_leaf);
-                cur = rate_of(flow_perm(fs, fbase + flow_chunks(nc_leaf), zero8(), d, false));
+                const Hash8 d = flow_sponge_capacity<PACE>(fs, fbase, w + m->qv_off[t] + row * nc_leaf, nc_leaf);
+                cur = rate_of(flow_perm<PACE>(fs, fbase + flow_chunks(nc_leaf), zero8(), d, false));
             } else
             cur = load_hash(rows + (size_t)row * 8);
             if (a.path_cols) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
                 const uint32_t lower = (t == 3 || A == B) ? 0u : umin(A, B);
                 const uint32_t extra = (lower && pl_ < lower) ? flow_chunks(lower == A ? plonk_cols(t) : poseidon_cols(t)) + 1u : 0u;
                 fidx = fbase + flow_chunks(nc_leaf) + 1u + (mx - lvl) + extra;
-                cur = rate_of(flow_perm(fs, fidx + (nc ? flow_chunks(nc) : 0u), cur, sib, odd));
+                cur = rate_of(flow_perm<PACE>(fs, fidx + (nc ? flow_chunks(nc) : 0u), cur, sib, odd));
             } else
             cur = hash_tree_swap<PACE>(cur, sib, odd);
             if (nc) {
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
                 if (off + nc > qv_n || nd_lower - 1 - row >= G) bad = true;
                 else {
                     if (FLOW && fs.rec) {  // hash_tree_with_column_hash_with_swap (merkle/src/lib.rs:32-41)
-                        const Hash8 colcap = flow_sponge_capacity(fs, fidx, w + m->qv_off[t] + off, nc);
-                        cur = rate_of(flow_perm(fs, fidx + flow_chunks(nc) + 1u, cur, colcap, false));
+                        const Hash8 colcap = flow_sponge_capacity<PACE>(fs, fidx, w + m->qv_off[t] + off, nc);
+                        cur = rate_of(flow_perm<PACE>(fs, fidx + flow_chunks(nc) + 1u, cur, colcap, false));
                     } else
                     cur = combine_with_column<PACE>(cur, load_hash(rows + ((size_t)G + (nd_lower - 1 - row)) * 8));
                     if (a.path_cols) {
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
             fbase = flow_pair_base(slot, m->nq, m->n_inner, m->last_n, m->A, m->B, M) + c->qperm[j] * flow_pair_path_len(slot, m->A, m->B, M);
         }
         if (FLOW && fs.rec) {  // hash_qm31_columns_get_rate(&[v, 0]) of the query's own value, then of its pair sibling's
-            cur = rate_of(flow_perm(fs, fbase + 1u, zero8(), flow_capacity4(fs, fbase, lv), false));
-            sibh = rate_of(flow_perm(fs, fbase + 3u, zero8(), flow_capacity4(fs, fbase + 2u, lv + 4), false));
+            cur = rate_of(flow_perm<PACE>(fs, fbase + 1u, zero8(), flow_capacity4<PACE>(fs, fbase, lv), false));
+            sibh = rate_of(flow_perm<PACE>(fs, fbase + 3u, zero8(), flow_capacity4<PACE>(fs, fbase + 2u, lv + 4), false));
         } else {
         cur = leaf_from_capacity<PACE>(sponge_capacity4<PACE>(lv[0], lv[1], lv[2], lv[3]));
         sibh = leaf_from_capacity<PACE>(sponge_capacity4<PACE>(lv[4], lv[5], lv[6], lv[7]));
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
             // already passed): swap-permute alone, or [self column capacity, sibling column capacity, swap-permute,
             // combine self, combine sibling] when the parent level carries a column
             fidx = fbase + 4u + (top - lvl) + 4u * dslot;
-            if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + (dg >= 0 ? 2u : 0u), cur, sibh, odd));
+            if (FLOW && fs.rec) cur = rate_of(flow_perm<PACE>(fs, fidx + (dg >= 0 ? 2u : 0u), cur, sibh, odd));
             else
             cur = hash_tree_swap<PACE>(cur, sibh, odd);
             have_sib = false;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
         if (on && dg >= 0) {
             const uint32_t* lv = leafv + ((size_t)dg * G + j) * 8;
             if (a.pair_sib || FLOW) store_hash(xch2[tid], cur);  // hash of this node's children, before the column
-            if (FLOW && fs.rec) cur = rate_of(flow_perm(fs, fidx + 3u, cur, flow_capacity4(fs, fidx, lv), false));
+            if (FLOW && fs.rec) cur = rate_of(flow_perm<PACE>(fs, fidx + 3u, cur, flow_capacity4<PACE>(fs, fidx, lv), false));
             else
             cur = combine_with_column<PACE>(cur, sponge_capacity4<PACE>(lv[0], lv[1], lv[2], lv[3]));
             store_hash(xcol[tid], cur);
@@ -578,14 +578,14 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
                     sibh = load_hash(xcol[gbase + ent_sib(e)]);
                     if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, load_hash(xch2[gbase + ent_sib(e)]));
                     if (FLOW && fs.rec)  // the circuit combines sibling_hashes[i] with the sibling's column itself
-                        sibh = rate_of(flow_perm(fs, fidx + 4u, load_hash(xch2[gbase + ent_sib(e)]), flow_capacity4(fs, fidx + 1u, lv + 4), false));
+                        sibh = rate_of(flow_perm<PACE>(fs, fidx + 4u, load_hash(xch2[gbase + ent_sib(e)]), flow_capacity4<PACE>(fs, fidx + 1u, lv + 4), false));
                 } else bad = true;
             } else if (w_sib + 1 < L->hash_n) {
                 const Hash8 wl = load_hash(w + L->hash_off + 8 * w_sib), wr = load_hash(w + L->hash_off + 8 * (w_sib + 1));
                 if (hash_over(wl) | hash_over(wr)) atomicOr(&a.ctxs[p].flags, 1u << R_PARSE);
                 Hash8 sn = hash_tree<PACE>(wl, wr);
                 if (psib) store_hash(psib + (size_t)(top - 1 - pl_) * 8, sn);
-                if (FLOW && fs.rec) sibh = rate_of(flow_perm(fs, fidx + 4u, sn, flow_capacity4(fs, fidx + 1u, lv + 4), false));
+                if (FLOW && fs.rec) sibh = rate_of(flow_perm<PACE>(fs, fidx + 4u, sn, flow_capacity4<PACE>(fs, fidx + 1u, lv + 4), false));
                 else
                 sibh = combine_with_column<PACE>(sn, sponge_capacity4<PACE>(lv[4], lv[5], lv[6], lv[7]));
             } else bad = true;

@@ -114,7 +114,9 @@ __device__ __forceinline__ void flow_put(const FlowSink& f, uint32_t idx, const 
     for (int k = 0; k < 4; k++) q[4 + k] = make_uint4(out.s[4 * k], out.s[4 * k + 1], out.s[4 * k + 2], out.s[4 * k + 3]);
     f.swap[idx] = (uint8_t)swap;
 }
-// permute(left, right, swap) with its record: returns the output state
+// permute(left, right, swap) with its record: returns the output state.  PACE: the permutation instance (1 the paced lane
+// form, FORM_ROW the row form on virtual lanes: the 16 threads of a row then write the same record)
+template <int PACE = 1>
 __device__ inline State16 flow_perm(const FlowSink& f, uint32_t idx, const Hash8& l, const Hash8& r, bool swap) {
     State16 st;
 #pragma unroll
@@ -122,26 +124,28 @@ __device__ inline State16 flow_perm(const FlowSink& f, uint32_t idx, const Hash8
         st.s[i] = swap ? r.w[i] : l.w[i];
         st.s[8 + i] = swap ? l.w[i] : r.w[i];
     }
-    st = poseidon2(st);
+    st = poseidon2_full<PACE>(st);
     flow_put(f, idx, l, r, st, swap ? 1u : 0u);
     return st;
 }
 // hash_m31_columns_get_capacity with records idx, idx + 1, ... (one per 8-word chunk)
+template <int PACE = 1>
 __device__ inline Hash8 flow_sponge_capacity(const FlowSink& f, uint32_t idx, const uint32_t* cols, uint32_t n) {
     Hash8 d = zero8();
     for (uint32_t off = 0; off < n; off += 8) {
         Hash8 chunk;
 #pragma unroll
         for (int i = 0; i < 8; i++) chunk.w[i] = (off + i < n) ? cols[off + i] : 0u;
-        d = cap_of(flow_perm(f, idx++, chunk, d, false));
+        d = cap_of(flow_perm<PACE>(f, idx++, chunk, d, false));
     }
     return d;
 }
 // hash_qm31_columns_get_capacity(&[v, 0]): one record
+template <int PACE = 1>
 __device__ inline Hash8 flow_capacity4(const FlowSink& f, uint32_t idx, const uint32_t* v) {
     Hash8 chunk = zero8();
     chunk.w[0] = v[0]; chunk.w[1] = v[1]; chunk.w[2] = v[2]; chunk.w[3] = v[3];
-    return cap_of(flow_perm(f, idx, chunk, zero8(), false));
+    return cap_of(flow_perm<PACE>(f, idx, chunk, zero8(), false));
 }
 
 // ChannelVar (primitives/channel/src/lib.rs:24-58).  PACE: the permutation instance its operations call (poseidon2.hpp)

@@ -449,6 +449,7 @@ __device__ __forceinline__ RowRC load_row_rc(uint32_t i) {
 }
 template <bool HI>
 __device__ __noinline__ Hash8 poseidon2_row_half(State16 st);
+__device__ __noinline__ State16 poseidon2_row_state(State16 st);  // the whole output state (PoseidonFlow records)
 // The row form's round constants for the out-of-line instance, in LDS: [round][lane of the row].  A kernel that calls
 // poseidon2_half<FORM_ROW> fills the table first (row_rc_init).  Not global memory: a load inside the callee would make it
 // wait for every load its caller has in flight (the memory counter is in order; LDS has a counter of its own) — the tree
@@ -469,6 +470,12 @@ template <int PACE = 1>
 __device__ __forceinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {  // hi is a literal at every call site
     if constexpr (PACE == FORM_ROW) return hi ? poseidon2_row_half<true>(st) : poseidon2_row_half<false>(st);
     else return hi ? poseidon2_half_t<true, PACE != 0>(st) : poseidon2_half_t<false, PACE != 0>(st);
+}
+// whole output state, by form (the PoseidonFlow kernels: lane form paced, or the row form)
+template <int PACE = 1>
+__device__ __forceinline__ State16 poseidon2_full(State16 st) {
+    if constexpr (PACE == FORM_ROW) return poseidon2_row_state(st);
+    else return poseidon2(st);
 }
 // the lane of a kernel's own indexing: a thread (lane forms) or a DPP row of 16 threads that all compute the same (row form)
 template <int PACE>

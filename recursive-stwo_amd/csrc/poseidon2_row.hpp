@@ -175,6 +175,24 @@ __device__ __forceinline__ uint32_t lane_select(uint32_t a, uint32_t b, uint64_t
     return r;
 }
 
+// the row's permutation of a state that every lane of the row holds: lane i takes word i and returns output word i
+__device__ __forceinline__ uint32_t poseidon2_row_of_state(const State16& st) {
+    const uint32_t i = threadIdx.x & 15u;  // (workgroups are multiples of 64 threads: rows are aligned)
+    RowRC k;                               // issued first: the first constant is needed ~45 instructions on
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.f[r] = s_row_rc[r][i];
+    // (asm: written as ?: the compiler sees sixteen values picked by an index, stores the state to scratch memory and
+    // loads one word back — a memory round trip per permutation and scratch in every kernel that calls this)
+    uint32_t a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = lane_select(st.s[2 * j], st.s[2 * j + 1], 0xAAAAAAAAAAAAAAAAull);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = lane_select(a[2 * j], a[2 * j + 1], 0xCCCCCCCCCCCCCCCCull);
+#pragma unroll
+    for (int j = 0; j < 2; j++) c[j] = lane_select(b[2 * j], b[2 * j + 1], 0xF0F0F0F0F0F0F0F0ull);
+    return poseidon2_row(lane_select(c[0], c[1], 0xFF00FF00FF00FF00ull), i, k);
+}
+
 // poseidon2_half on a "virtual lane" (poseidon2.hpp): every lane of the row passes the same state and receives the same
 // half of the output.  Lane i takes word i of the state (four levels of selects on the bits of i), the row permutes, and
 // the eight output words are read back from the lanes that hold them (row_share).  The callers' control flow is uniform
@@ -190,26 +208,33 @@ __device__ __noinline__ Hash8 poseidon2_row_half(State16 st) {
         }
     }
 #endif
-    const uint32_t i = threadIdx.x & 15u;  // (workgroups are multiples of 64 threads: rows are aligned)
-    RowRC k;                               // issued first: the first constant is needed ~45 instructions on
-#pragma unroll
-    for (int r = 0; r < 8; r++) k.f[r] = s_row_rc[r][i];
-    // (asm: written as ?: the compiler sees sixteen values picked by an index, stores the state to scratch memory and
-    // loads one word back — a memory round trip per permutation and scratch in every kernel that calls this)
-    uint32_t a[8], b[4], c[2];
-#pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = lane_select(st.s[2 * j], st.s[2 * j + 1], 0xAAAAAAAAAAAAAAAAull);
-#pragma unroll
-    for (int j = 0; j < 4; j++) b[j] = lane_select(a[2 * j], a[2 * j + 1], 0xCCCCCCCCCCCCCCCCull);
-#pragma unroll
-    for (int j = 0; j < 2; j++) c[j] = lane_select(b[2 * j], b[2 * j + 1], 0xF0F0F0F0F0F0F0F0ull);
-    const uint32_t y = poseidon2_row(lane_select(c[0], c[1], 0xFF00FF00FF00FF00ull), i, k);
+    const uint32_t y = poseidon2_row_of_state(st);
     Hash8 h;
     h.w[0] = row_share<(HI ? 8 : 0) + 0>(y); h.w[1] = row_share<(HI ? 8 : 0) + 1>(y);
     h.w[2] = row_share<(HI ? 8 : 0) + 2>(y); h.w[3] = row_share<(HI ? 8 : 0) + 3>(y);
     h.w[4] = row_share<(HI ? 8 : 0) + 4>(y); h.w[5] = row_share<(HI ? 8 : 0) + 5>(y);
     h.w[6] = row_share<(HI ? 8 : 0) + 6>(y); h.w[7] = row_share<(HI ? 8 : 0) + 7>(y);
     return h;
+}
+
+// the whole output state in every lane of the row (the PoseidonFlow kernels' records hold all sixteen words)
+__device__ __noinline__ State16 poseidon2_row_state(State16 st) {
+#ifdef RSV_COUNT_PERMS
+    {
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m) / 16ull);
+            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
+        }
+    }
+#endif
+    const uint32_t y = poseidon2_row_of_state(st);
+    State16 o;
+    o.s[0] = row_share<0>(y); o.s[1] = row_share<1>(y); o.s[2] = row_share<2>(y); o.s[3] = row_share<3>(y);
+    o.s[4] = row_share<4>(y); o.s[5] = row_share<5>(y); o.s[6] = row_share<6>(y); o.s[7] = row_share<7>(y);
+    o.s[8] = row_share<8>(y); o.s[9] = row_share<9>(y); o.s[10] = row_share<10>(y); o.s[11] = row_share<11>(y);
+    o.s[12] = row_share<12>(y); o.s[13] = row_share<13>(y); o.s[14] = row_share<14>(y); o.s[15] = row_share<15>(y);
+    return o;
 }
 
 }  // namespace rsv

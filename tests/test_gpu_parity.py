@@ -569,9 +569,12 @@ def test_tree_kernel_forms_match_oracle(rsv, knobs, pace, order):
     assert acc3.tolist() == o1.tolist() and reason3.tolist() == r1.tolist()
 
 
+@pytest.mark.parametrize("trees", ["paced", "row16"])
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])
-def test_trace_paths_match_oracle(rsv, manifest, name):
-    """per-query authentication paths (transcript order) emitted by the GPU == oracle's."""
+def test_trace_paths_match_oracle(rsv, manifest, knobs, name, trees):
+    """per-query authentication paths (transcript order) emitted by the GPU == oracle's; from the lane form and
+    from the row form of the tree kernels (what a batch of two proofs takes by itself)."""
+    knobs.set("tree_pace", trees)
     entry = next(e for e in manifest if e["file"] == name)
     proof = read_proof(name)
     nq = entry["n_queries"]
@@ -673,9 +676,12 @@ def test_transcript_in_one_piece_and_split(rsv, knobs, split, form):
     assert acc.tolist() == oacc.tolist() == [0, 0, 0, 0, 1] and reason.tolist() == oreason.tolist() == [1, 1, 1, 1, 0]
 
 
+@pytest.mark.parametrize("trees", ["paced", "row16"])
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level13-1.bin"])
-def test_fri_paths_match_oracle(rsv, manifest, name):
-    """per-query pair paths of every FRI tree (transcript order) emitted by the GPU == oracle's."""
+def test_fri_paths_match_oracle(rsv, manifest, knobs, name, trees):
+    """per-query pair paths of every FRI tree (transcript order) emitted by the GPU == oracle's; lane form and
+    row form of the tree kernels."""
+    knobs.set("tree_pace", trees)
     entry = next(e for e in manifest if e["file"] == name)
     proof = read_proof(name)
     lay = ob.proof_layout(proof)
@@ -1339,9 +1345,10 @@ def test_qconst_kernels_row_and_lane(rsv, manifest, knobs, mode):
 FLOW_SHAPES = ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level1-5.bin", "level9-1.bin", "level13-1.bin"]
 
 
+@pytest.mark.parametrize("trees", ["paced", "row16"])
 @pytest.mark.parametrize("form", ["row", "lane", "lane, every lane walks to the root"])
 @pytest.mark.parametrize("name", FLOW_SHAPES)
-def test_poseidon_flow_matches_oracle(rsv, manifest, knobs, name, form):
+def test_poseidon_flow_matches_oracle(rsv, manifest, knobs, name, form, trees):
     """SURVEY 8f.1, second half: the PoseidonFlow records the verifying pass writes (rsv_hints_out::d_flow) == the
     oracle's, which runs the reference's per-path verifiers in the circuit's invocation order with a recorder on its
     permutation (oracle/rsv_oracle.c: rsvo_poseidon_flow).  Seven shapes: n_queries 8 / 11 / 16 / 27 / 80, equal and
@@ -1350,8 +1357,11 @@ def test_poseidon_flow_matches_oracle(rsv, manifest, knobs, name, form):
     the transcript kernel write the channel's records: one proof per 16-lane row (small batches) and one proof per lane."""
     # default: the top-of-tree cap hashes a node several queries share ONCE and writes every query's record from there;
     # flow_cap = off: every lane hashes (and records) its whole path itself
+    # trees: the flow-writing tree kernels in the lane form and in the row form on virtual lanes (16 threads write each
+    # record; what a three-proof call takes by itself; the 80-query shape falls back to the lane form)
     knobs.set("transcript_form", form.split(",")[0])
     knobs.set("flow_cap", "off" if "," in form else "auto")
+    knobs.set("tree_pace", trees)
     entry = next(e for e in manifest if e["file"] == name)
     proof, inputs, cfg = read_proof(name), entry_inputs(entry), fixture_cfg(name)
     want = ob.poseidon_flow(proof, inputs)

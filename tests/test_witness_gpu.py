@@ -384,6 +384,15 @@ def test_witness_launch_forms_agree(rsv):
             ctx.synchronize()
             assert d_acc.cpu().numpy().tolist() == good.astype(int).tolist(), (n, small_max, small_log, walk_log)
             assert (d_vars.cpu().numpy().view(np.uint32)[good] == want[None]).all(), (n, small_max, small_log, walk_log)
+        # the verifying pass's tree kernels in the lane form and in the row form (what batches this small take by themselves)
+        for trees in ("paced", "row16", "auto"):
+            ctx.set_option("tree_pace", trees)
+            d_vars = torch.full((n, wp.n_vars, 4), -1, dtype=torch.int32, device=dev)
+            d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+            ctx.witness(wp, d_blob, d_off, n, d_vars, d_acc, inputs=_inputs(name))
+            ctx.synchronize()
+            assert d_acc.cpu().numpy().tolist() == good.astype(int).tolist(), (n, trees)
+            assert (d_vars.cpu().numpy().view(np.uint32)[good] == want[None]).all(), (n, trees)
     for opt, v in (("witness_small_max", (1 << 20) + 2), ("witness_small_log", 8), ("witness_small_max", -1), ("witness_walk_log", 8)):
         with pytest.raises(rsv.RsvError):
             ctx.set_option(opt, v)
