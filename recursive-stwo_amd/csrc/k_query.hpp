@@ -47,7 +47,10 @@ __device__ inline QM31 fold_pair(QM31 self, QM31 sib, bool odd, uint32_t inv_coo
 // No array here is indexed at run time: the factors are brought into index-bit order by a 4-stage barrel shift of
 // registers.  (A run-time index put d[] in scratch memory, and a kernel that uses scratch costs ~15 us more per launch on
 // this part — tools/chain_lab.hip — which a small batch pays in full: k_query is on its chain of dependent kernels.)
-__device__ __forceinline__ QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x) {
+// hi0, hi_step: this call's share of the blocks of 16 coefficients (the row form of k_query splits them over 16 threads and
+// adds the partial sums up; default: all of them)
+__device__ __forceinline__ QM31 line_eval(const uint32_t* __restrict__ cf, uint32_t log_n, uint32_t n, uint32_t x, uint32_t hi0 = 0,
+                                          uint32_t hi_step = 1) {
     // r[15 - j] = pi^j(x); index bit b of a coefficient pairs with pi^(log_n-1-b)(x) = r[b + 16 - log_n]
     uint32_t r[16];
 #pragma unroll
@@ -77,7 +80,7 @@ __device__ __forceinline__ QM31 line_eval(const uint32_t* __restrict__ cf, uint3
     QM31 acc = q_zero();
     const uint32_t n_hi = n >> nlo, n_lo = 1u << nlo;
 #pragma unroll 1
-    for (uint32_t hi = 0; hi < n_hi; hi++) {
+    for (uint32_t hi = hi0; hi < n_hi; hi += hi_step) {
         // hi > 0 only when log_n > 4, i.e. nlo = 4: bit b of hi is index bit b + 4
         uint32_t wh = 1u;
 #pragma unroll
@@ -103,21 +106,30 @@ __device__ __forceinline__ bool last_layer_ok(QM31 eval, QM31 folded) { return q
 // batches, where this kernel is on the step's chain of dependent kernels: 1 024 proofs 1.556 -> 1.532 ms) at 104-114
 // registers = 4 waves per SIMD; 2 keeps 96 registers = 5 waves per SIMD for the large batches that run it underneath the
 // trace trees (65 536 proofs: 34.13 ms against 34.87 with 4).
-template <int BLOCK, uint32_t QB>
+// ROW: the kernel on VIRTUAL lanes, as the row form of the tree kernels (k_merkle.hpp) — a DPP row of 16 threads per query.
+// They compute the same indices and the same folds; what is a sum they split: the 142 columns of the quotients' linear
+// combinations and the blocks of the last-layer polynomial go sixteen ways and are added up over the row.  For launches
+// of a few waves (with the trees' row form): one proof's k_query 95 -> 47 us (of the 95: last layer 42, quotients 33, inner layers 20), 128 proofs 112 -> 71 us.
+template <int BLOCK, uint32_t QB, bool ROW = false>
 __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
-    __shared__ uint32_t xq[BLOCK][4];
+    constexpr int VB = ROW ? BLOCK / 16 : BLOCK;                       // lanes of this kernel's indexing per workgroup
+    const uint32_t tid = ROW ? threadIdx.x >> 4 : threadIdx.x;         // the lane of the indexing below
+    const uint32_t part = ROW ? threadIdx.x & 15u : 0u;                // ROW: this thread's sixteenth of a query's sums
+    // sum of a QM31 over the 16 threads of a row, in every one of them
+    auto row_sum_q = [](QM31 v) { return q_mk(sum_row(v.a.a), sum_row(v.a.b), sum_row(v.b.a), sum_row(v.b.b)); };
+    __shared__ uint32_t xq[VB][4];
     // each lane's first-layer folds (one QM31 per column size), word-major so that a wave's access is conflict free.  In
     // LDS, not registers: they are written early and read in the inner-layer loop, and 12 more live registers would cost
     // the kernel its fifth wave per SIMD.  (Indexed arrays in registers end up in scratch memory, which costs a small
     // batch ~15 us per launch: tools/chain_lab.hip.)
-    __shared__ uint32_t fst[3][4][BLOCK];
-    __shared__ uint32_t dps[3][2][BLOCK];  // and its domain point at each column size (x, y), for the same reason
+    __shared__ uint32_t fst[3][4][VB];
+    __shared__ uint32_t dps[3][2][VB];  // and its domain point at each column size (x, y), for the same reason
     // The FRI trees wait for this kernel while it shares the machine with the trace trees: its waves go first in the
     // SIMDs' arbitration, so that it is over in a fraction of the trace trees' time and the FRI trees start beside them.
     __builtin_amdgcn_s_setprio(3);
     RSV_FUSED_SELECT(f, a, bx);
-    const uint32_t G = a.pl.G, per_block = BLOCK / G;
-    const uint32_t grp = threadIdx.x / G, j = threadIdx.x % G;
+    const uint32_t G = a.pl.G, per_block = VB / G;
+    const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot = bx * per_block + grp;
     bool live = grp < per_block && slot < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot) : 0u;
@@ -135,9 +147,9 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     uint32_t* qv = (live && a.qv_out) ? a.qv_out + ((size_t)slot * G + c->qperm[j]) * a.qv_stride : nullptr;
     uint32_t n_sizes = live ? c->n_sizes : 0;
     auto put_first = [&](uint32_t g, QM31 v) {
-        fst[g][0][threadIdx.x] = v.a.a; fst[g][1][threadIdx.x] = v.a.b; fst[g][2][threadIdx.x] = v.b.a; fst[g][3][threadIdx.x] = v.b.b;
+        fst[g][0][tid] = v.a.a; fst[g][1][tid] = v.a.b; fst[g][2][tid] = v.b.a; fst[g][3][tid] = v.b.b;
     };
-    auto get_first = [&](uint32_t g) { return q_mk(fst[g][0][threadIdx.x], fst[g][1][threadIdx.x], fst[g][2][threadIdx.x], fst[g][3][threadIdx.x]); };
+    auto get_first = [&](uint32_t g) { return q_mk(fst[g][0][tid], fst[g][1][tid], fst[g][2][tid], fst[g][3][tid]); };
     // Domain points.  One scalar multiplication gives the point of the query at level M; the points at the
     // smaller column sizes follow by the doubling map pi(x, y) = (2x^2 - 1, 2xy): doubling the level-l point of
     // position pos gives the level-(l-1) point of pos >> 1 up to the sign of y, which is fixed by bit 0 of the
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                 cur.y = ((pos ^ (pos >> 1)) & 1u) ? m_neg(y2) : y2;
                 lvl--;
             }
-            dps[g][0][threadIdx.x] = cur.x; dps[g][1][threadIdx.x] = cur.y;
+            dps[g][0][tid] = cur.x; dps[g][1][tid] = cur.y;
         };
         descend(0); descend(1); descend(2);
     }
@@ -191,6 +203,18 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                     // iteration is consumed at once, and the lane then pays the whole memory latency 134 times (a single
                     // proof: 0.11 ms of a 1.3 ms call).  Interaction columns 4-7 / 12-15 (k & 4) carry a second sample
                     // point: a batch starts at a multiple of 4, so a whole batch has one or none.
+                    if constexpr (ROW) {
+                        // this thread's columns: part, part + 16, ...  Column k of the segment reads alpha power col + k; in an
+                        // interaction tree the columns with (k & 4) carry the second sample point, whose powers are numbered
+                        // in column order: 4 * (k >> 3) + (k & 3) such columns come before column k
+                        for (uint32_t k = part; k < nc; k += 16u) {
+                            const uint32_t v = inb ? qv[off + k] : 0u;
+                            r0 = q_add(r0, q_mul_m(ldq(c->apow[col + k]), v));
+                            if (t == 2 && (k & 4u)) r1 = q_add(r1, q_mul_m(ldq(c->apow[ncols_group + dbl + 4u * (k >> 3) + (k & 3u)]), v));
+                        }
+                        col += nc;
+                        if (t == 2) dbl += 4u * (nc >> 3) + ((nc & 7u) > 4u ? (nc & 7u) - 4u : 0u);
+                    } else
                     for (uint32_t k0 = 0; k0 < nc; k0 += QB) {
                         const bool twice = t == 2 && (k0 & 4);
                         uint32_t vv[QB];
@@ -215,7 +239,8 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                     }
                 }
             }
-            const CPoint dpg = {dps[g][0][threadIdx.x], dps[g][1][threadIdx.x]};  // read here, not above: not live over the columns
+            if constexpr (ROW) { r0 = row_sum_q(r0); r1 = row_sum_q(r1); }  // the sixteen threads' shares
+            const CPoint dpg = {dps[g][0][tid], dps[g][1][tid]};  // read here, not above: not live over the columns
             dpg_y = dpg.y;
             for (uint32_t bi = 0; bi < c->n_batches[g]; bi++) {
                 const QBatch& qb = c->batch[g][bi];
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
             }
         }
         // exchange answers: the pair sibling may be another query of this proof
-        stq(xq[threadIdx.x], answer);
+        stq(xq[tid], answer);
         __syncthreads();
         if (on) {
             uint32_t e = ent[l * G + j];
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     // the bit-reversed index by half the coset = the point (-1, 0), i.e. negates x).
     QM31 folded = q_zero();
     uint32_t l = M;
-    uint32_t X = live ? dps[0][0][threadIdx.x] : 0u;  // x of the query's point at the largest column size
+    uint32_t X = live ? dps[0][0][tid] : 0u;  // x of the query's point at the largest column size
     for (uint32_t i = 0; i < a.maxInner; i++) {
         bool on = live && i < m->n_inner;
         if (on) {
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
                 }
             l -= 1;
         }
-        stq(xq[threadIdx.x], folded);
+        stq(xq[tid], folded);
         __syncthreads();
         if (on) {
             uint32_t pos = qj >> (M - l);
@@ -296,7 +321,8 @@ __global__ __launch_bounds__(BLOCK) void k_query(Fused<QueryArgs> f) {
     // ---- last layer (folding/src/lib.rs:194-204, primitives/line/src/lib.rs:39-67)
     if (live) {
         // x of half_odds(l-1).at(bit_reverse(pos >> 1)) = pi(X_l) (for a proof without inner layers: pi of x_M)
-        QM31 acc = line_eval(w + m->last_off, m->log_last, m->last_n, m_sub(m_dbl(m_sqr(X)), 1u));
+        QM31 acc = line_eval(w + m->last_off, m->log_last, m->last_n, m_sub(m_dbl(m_sqr(X)), 1u), part, ROW ? 16u : 1u);
+        if constexpr (ROW) acc = row_sum_q(acc);
         if (!last_layer_ok(acc, folded)) flags |= 1u << R_FRI_LAST;
         if (qv) { stq(qv + 24 + 4 * a.maxInner, folded); stq(qv + 28 + 4 * a.maxInner, acc); }
     }

@@ -1172,11 +1172,14 @@ def test_oods_eval_probe_matches_oracle(rsv, manifest):
 
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level7-1.bin", "level2-1.bin", "level1-5.bin",
                                   "level10-1.bin", "level13-1.bin"])
-def test_query_values_match_oracle(rsv, manifest, name):
+@pytest.mark.parametrize("trees", ["paced", "row16"])
+def test_query_values_match_oracle(rsv, manifest, knobs, name, trees):
     """Rows a11 / a12 by VALUE (not only by verdict): the DEEP-quotient answers at every column log size, their
     circle-to-line folds, the value entering every inner FRI layer, the value entering the last-layer check and the
-    last-layer evaluation, per query, from the verifying pass == the oracle's."""
+    last-layer evaluation, per query, from the verifying pass == the oracle's.  trees: with the row form of the tree kernels
+    (what a single proof takes by itself) k_query runs on virtual lanes too — 16 threads per query that split its sums."""
     import torch
+    knobs.set("tree_pace", trees)
     entry = next(e for e in manifest if e["file"] == name)
     proof = read_proof(name)
     lay = ob.proof_layout(proof)
