@@ -47,6 +47,7 @@ struct Options {
     int graph = 0;             // 0 / 2 off, 1 replay repeated identical calls as a HIP graph (experiment)
     int witness_layout = 0;    // 0 / 1 d_variables [proof][variable], 2 [variable][proof]
     int flow_cap = 0;          // PoseidonFlow passes: 0 / 1 top-of-tree cap (shared nodes hashed once), 2 every lane walks to the root
+    int query_form = 0;        // 0 auto (by batch size), 1 k_query with a row of 16 threads per query, 2 with one lane per query
     int stage_times = 0;       // 0 / 2 off, 1 record an event pair around every stage (rsv_last_stage_times)
     int tree_pace = 0;         // 0 auto (by batch size), 1 the tree kernels on the paced permutation instances, 2 on the unpaced ones, 3 in the row form (16 threads per path)
     int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
@@ -255,6 +256,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_PAIR_ORDER: return tri(&o.pair_order);
         case RSV_OPT_TREE_PACE: if (value < 0 || value > 3) return (int)RSV_E_RANGE; o.tree_pace = (int)value; return (int)RSV_OK;
         case RSV_OPT_STAGE_TIMES: return tri(&o.stage_times);
+        case RSV_OPT_QUERY_FORM: return tri(&o.query_form);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;
             o.witness_walk_log = (int)value; return RSV_OK;

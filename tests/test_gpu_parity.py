@@ -1180,6 +1180,7 @@ def test_query_values_match_oracle(rsv, manifest, knobs, name, trees):
     (what a single proof takes by itself) k_query runs on virtual lanes too — 16 threads per query that split its sums."""
     import torch
     knobs.set("tree_pace", trees)
+    knobs.set("query_form", "lane" if trees == "paced" else "row")
     entry = next(e for e in manifest if e["file"] == name)
     proof = read_proof(name)
     lay = ob.proof_layout(proof)
