@@ -249,29 +249,33 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     }
     }  // PHASE != 2
     if (PHASE == 2 && !rate) dg = c.pow_digest[i - 8];
+    // The parser's findings in registers: `m` is global memory and the channel's stores (challenges, flow records) may alias
+    // it as far as the compiler knows, so m.last_n / m.last_off were re-read in every iteration of the last-layer loop — a
+    // dependent load in front of each of its 128 permutations (back half 2.53 us per permutation against the front's 2.04).
+    const uint32_t last_n = m.last_n, last_off = m.last_off, n_inner = m.n_inner, nq = m.nq, pow_bits = m.pow_bits, nonce_off = m.nonce_off;
     const uint32_t first_commit = word_of(w + m.first.commit_off, 8);
     // the words of the last-layer polynomial that one mix absorbs (odd tail: second felt = 0)
     auto last_word = [&](uint32_t k) {
-        const uint32_t left = 4 * (m.last_n - k);
-        return word_of(w + m.last_off + 4 * k, left < 8 ? left : 8u);
+        const uint32_t left = 4 * (last_n - k);
+        return word_of(w + last_off + 4 * k, left < 8 ? left : 8u);
     };
-    nxt = m.n_inner ? word_of(w + m.inner[0].commit_off, 8) : (m.last_n ? last_word(0) : 0u);
+    nxt = n_inner ? word_of(w + m.inner[0].commit_off, 8) : (last_n ? last_word(0) : 0u);
     mix(first_commit);
     out = draw();
     store_felt(c.fri_alpha[0], out);
 #pragma unroll 1
-    for (uint32_t l = 0; l < m.n_inner; l++) {
+    for (uint32_t l = 0; l < n_inner; l++) {
         const uint32_t cur = nxt;
-        nxt = l + 1 < m.n_inner ? word_of(w + m.inner[l + 1].commit_off, 8) : (m.last_n ? last_word(0) : 0u);
+        nxt = l + 1 < n_inner ? word_of(w + m.inner[l + 1].commit_off, 8) : (last_n ? last_word(0) : 0u);
         mix(cur);
         out = draw();
         store_felt(c.fri_alpha[l + 1], out);
     }
-    const uint32_t nonce_lo = w[m.nonce_off], nonce_hi = w[m.nonce_off + 1];
+    const uint32_t nonce_lo = w[nonce_off], nonce_hi = w[nonce_off + 1];
 #pragma unroll 1
-    for (uint32_t k = 0; k < m.last_n; k += 2) {  // fiat_shamir/src/lib.rs:94-100
+    for (uint32_t k = 0; k < last_n; k += 2) {  // fiat_shamir/src/lib.rs:94-100
         const uint32_t cur = nxt;
-        if (k + 2 < m.last_n) nxt = last_word(k + 2);
+        if (k + 2 < last_n) nxt = last_word(k + 2);
         mix(cur);
     }
     // nonce split 22/21/21: data_structures/src/lib.rs:197-213, fiat_shamir/src/lib.rs:102-113
@@ -282,16 +286,16 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     {
         uint32_t ov = sum_row(over);
         if (PHASE == 2) ov += c.front_over;
-        const uint32_t fl = ((dg & ((1u << m.pow_bits) - 1u)) ? (1u << R_POW) : 0u) | (ov ? (1u << R_PARSE) : 0u);  // fiat_shamir/src/lib.rs:115-117
+        const uint32_t fl = ((dg & ((1u << pow_bits) - 1u)) ? (1u << R_POW) : 0u) | (ov ? (1u << R_PARSE) : 0u);  // fiat_shamir/src/lib.rs:115-117
         if (i == 8 && fl) atomicOr(&c.flags, fl);  // k_parse zeroed it; k_row_hash may be raising bits beside this kernel
     }
 #pragma unroll 1
-    for (uint32_t got = 0; got < m.nq; got += 8) {  // fiat_shamir/src/lib.rs:119-130
+    for (uint32_t got = 0; got < nq; got += 8) {  // fiat_shamir/src/lib.rs:119-130
         out = draw();
-        if (rate && got + i < m.nq) c.raw_q[got + i] = out;
+        if (rate && got + i < nq) c.raw_q[got + i] = out;
     }
     if (FLOW)  // the circuit's surplus draws: same channel, no new value
-        for (uint32_t draws = (m.nq + 7u) / 8u; draws < (m.nq + 3u) / 4u; draws++) (void)draw();
+        for (uint32_t draws = (nq + 7u) / 8u; draws < (nq + 3u) / 4u; draws++) (void)draw();
 }
 
 }  // namespace rsv
