@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     // Every word the chain absorbs is fetched BEFORE the permutation that precedes its use: a load issued between
     // two permutations is consumed at once and costs the row its whole HBM latency (1-2 us, against 2-3 us for the
     // permutation itself).
-    // Everything word_of / sample_word fetch is a field element the transcript absorbs: checked for canonicity here,
+    // Everything word_of / sample_at fetch is a field element the transcript absorbs: checked for canonicity here,
     // where it is read (layout.hpp); the lanes' findings are added up over the row at the end.
     uint32_t over = 0;
     auto word_of = [&](const uint32_t* src, uint32_t n_words) {
@@ -199,8 +199,12 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
         return v;
     };
     auto store_felt = [&](uint32_t* dst, uint32_t out) { if (i < 4) dst[i] = out; };
-    auto sample_word = [&](int k) {
-        const uint32_t v = rate ? w[SAMPLES.off[k + (i >> 2)] + (i & 3u)] : 0u;
+    // where lane i's word of the sample pair (k, k + 1) sits, and the word itself.  The offset comes from a table and the
+    // word's address from the offset: fetched in the same round they are two dependent loads in front of a permutation
+    // (0.25 us of each of the 71), so the offset is fetched one round before the word (sample_at)
+    auto sample_off = [&](int k) { return rate ? (uint32_t)SAMPLES.off[k + (i >> 2)] + (i & 3u) : 0u; };
+    auto sample_at = [&](uint32_t off) {
+        const uint32_t v = rate ? w[off] : 0u;
         over |= v >= P;
         return v;
     };
@@ -209,7 +213,8 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
     const uint32_t c0 = word_of(w + W_COMMIT0, 8), c1 = word_of(w + W_COMMIT0 + 8, 8), c2 = word_of(w + W_COMMIT0 + 16, 8);
     const uint32_t c3 = word_of(w + W_COMMIT0 + 24, 8), sums = word_of(w + W_PLONK_SUM, 8);
     const uint32_t lp = w[W_LP], lq = w[W_LQ];  // == m.lp, m.lq once the parser has run
-    nxt = sample_word(0);
+    nxt = sample_at(sample_off(0));
+    uint32_t off_nxt = sample_off(2 < N_SAMPLES ? 2 : 0);
     mix(c0);
     mix(i == 0 ? lp : 0u);  // statement 0: data_structures/src/lib.rs:52-55
     mix(i == 0 ? lq : 0u);
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(256) void k_transcript_row(const uint8_t* __restric
 #pragma unroll 1
     for (int k = 0; k < N_SAMPLES; k += 2) {  // fiat_shamir/src/lib.rs:68-75
         const uint32_t cur = nxt;
-        if (k + 2 < N_SAMPLES) nxt = sample_word(k + 2);
+        if (k + 2 < N_SAMPLES) nxt = sample_at(off_nxt);
+        if (k + 4 < N_SAMPLES) off_nxt = sample_off(k + 4);
         mix(cur);
     }
     out = draw();
