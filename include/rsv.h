@@ -142,7 +142,7 @@ typedef enum rsv_option {
     RSV_OPT_TRANSCRIPT_FORM = 1,  /* 0 auto (by batch size), 1 one proof per 16-lane DPP row, 2 one proof per lane */
     RSV_OPT_TRANSCRIPT_SPLIT = 2, /* 0 auto, 1 one launch, 2 front half beside the parser + back half (row form only) */
     RSV_OPT_OODS_FORM = 3,        /* 0 auto, 1 row, 2 lane */
-    RSV_OPT_QCONST_FORM = 4,      /* 0 auto, 1 row, 2 lane */
+    RSV_OPT_QCONST_FORM = 4,      /* 0 auto (<= 4 096 proofs: four 16-lane rows per proof, <= 24 576: one row, else lane), 1 one row per proof, 2 lane */
     RSV_OPT_PLAN_FORM = 5,        /* 0 / 1 one lane per (proof, query), 2 one lane per proof */
     RSV_OPT_TREE_CAP = 6,         /* 0 / 1 dense top-of-tree cap, 2 every lane walks its path to the root */
     RSV_OPT_OVERLAP_TREES = 7,    /* 0 auto, 1 FRI trees beside the trace trees (single-group batches), 2 behind them */

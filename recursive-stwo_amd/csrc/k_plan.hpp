@@ -217,7 +217,7 @@ struct PlanArgs {
     PlanPtrs pl;
 };
 __device__ void qconst_row_body(uint32_t block, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets, uint32_t n,
-                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs);
+                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs, bool four);
 // QCONST (small batches, chain stream layout): the workgroups behind the plan's also compute the query-independent
 // quotient constants in their row form (k_qconst_row's body for qconst_n proofs) — both need only the transcript and
 // both precede k_query on the step's chain of dependent kernels, where a launch of its own costs 12-25 us.
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_par(const uint8_t* __restrict__ 
                                                     const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs,
                                                     Fused<PlanArgs> f, uint32_t qconst_n) {
     if (QCONST && blockIdx.x >= f.first_block[f.nb]) {
-        qconst_row_body(blockIdx.x - f.first_block[f.nb], blob, offsets, qconst_n, metas, ctxs);
+        qconst_row_body(blockIdx.x - f.first_block[f.nb], blob, offsets, qconst_n & 0x7FFFFFFFu, metas, ctxs, (qconst_n >> 31) != 0u);
         return;
     }
     RSV_FUSED_SELECT(f, pa, bx);
@@ -525,12 +525,16 @@ static_assert(make_qtab().n[3] <= N_APOW && make_qtab().n[3] == 134 && make_qtab
 __global__ __launch_bounds__(256) void k_qconst_row(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                                     uint32_t n, const ProofMeta* __restrict__ metas,
                                                     ProofCtx* __restrict__ ctxs) {
-    qconst_row_body(blockIdx.x, blob, offsets, n, metas, ctxs);
+    qconst_row_body(blockIdx.x, blob, offsets, n & 0x7FFFFFFFu, metas, ctxs, (n >> 31) != 0u);  // bit 31 of n: four rows per proof
 }
 __device__ void qconst_row_body(uint32_t block, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets, uint32_t n,
-                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs) {
-    const uint32_t i = threadIdx.x & 15u;
-    const uint32_t p = (block * blockDim.x + threadIdx.x) >> 4;
+                                const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs, bool four) {
+    // four: FOUR rows per proof — rows 0..2 take one column log size each, row 3 writes the alpha powers.  The three sums
+    // and the power table are independent chains of QM31 products; on one row after the other they were 31 us of a single
+    // proof's 37 us k_plan_par launch (the plan itself: 17 us).  For batches of a few thousand proofs (the host decides):
+    // 1 024 proofs 1.338 -> 1.323 ms, but 16 384 proofs 9.24 -> 9.29 (four times the waves, most of them a quarter full).
+    const uint32_t i = threadIdx.x & 15u, row = four ? (threadIdx.x >> 4) & 3u : 0u;
+    const uint32_t p = (block * blockDim.x + threadIdx.x) >> (four ? 6 : 4);
     if (p >= n) return;  // whole rows leave together (DPP needs every lane of a live row)
     const ProofMeta& m = metas[p];
     if (m.reason != R_OK) return;
@@ -551,18 +555,20 @@ __device__ void qconst_row_body(uint32_t block, const uint8_t* __restrict__ blob
     start = q_mul(start, sel(i & 4u, a4, one));
     start = q_mul(start, sel(i & 8u, a8, one));
     start = q_mul(start, q_mk(0, 0, m_neg(2), 0));
-    {
+    if (!four || row == 3u) {
         QM31 cur = start;
 #pragma unroll 1
         for (uint32_t k = i; k < (uint32_t)N_APOW; k += 16u) { stq(c.apow[k], cur); cur = q_mul(cur, a16); }
+        if (four) return;
     }
+    if (four && row >= n_sizes) return;
     const QM31 ox = ldq(c.oods_x), oy = ldq(c.oods_y);
-    for (uint32_t g = 0; g < n_sizes; g++) {
+    for (uint32_t g = four ? row : 0u; g < (four ? row + 1u : n_sizes); g++) {
         const uint32_t l = sizes[g];
         const uint32_t kind = l == M ? 0u : (A == B ? 3u : (l == A ? 1u : 2u));
         // batch 0: OODS point; batch 1: OODS - g_{component log size} (answer/src/lib.rs:62-72)
         const uint32_t comp_log = (l == A) ? m.lp : m.lq;
-        CPoint step = cp_gen_mul(1u << (31u - comp_log));
+        CPoint step = {GEN_POW.x[31u - comp_log], GEN_POW.y[31u - comp_log]};  // = cp_gen_mul(1 << (31 - comp_log)); the parser admits 1 <= lp, lq <= 28
         step.y = m_neg(step.y);
         const QM31 sx = q_sub(q_mul_m(ox, step.x), q_mul_m(oy, step.y));
         const QM31 sy = q_add(q_mul_m(ox, step.y), q_mul_m(oy, step.x));
