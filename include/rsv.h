@@ -174,7 +174,7 @@ typedef enum rsv_option {
                                      instance with wait states behind its multiplies (pays with several waves per SIMD), 2 the one
                                      without (a wave nearly alone), 3 the row form: 16 threads per Merkle path share every permutation
                                      (a launch of a few waves: the walk is a chain of dependent permutations, the row form's a
-                                     quarter as long); not with per-query path outputs or more than 32 queries (then: 2) */
+                                     quarter as long); not with more than 32 queries (then: 2, or 1 when the flow is written) */
     RSV_OPT_QUERY_FORM = 25,      /* 0 auto (by batch size), 1 the quotient / fold kernel with a row of 16 threads per query that split its sums
                                      (chain layout only; not with more than 32 queries), 2 with one lane per query */
     RSV_OPT_STAGE_TIMES = 24,     /* 0 / 2 off; 1 record a HIP event pair around every stage of a verify call, which is what
