@@ -109,6 +109,14 @@ def main():
                 calls += 1
         print(f"small: {calls} one-configuration calls of 5..64 proofs, mismatches {small}")
         bad += small
+        # every configuration's proofs in ONE call: with trailing tree_pace=row16 query_form=row this is the row forms on
+        # launches of hundreds to thousands of proofs (many workgroups, the in-kernel cap, k_cap_top behind it)
+        whole = 0
+        for ix in by_cfg.values():
+            a, r = rsv.verify_batch([batch[i] for i in ix], cfgs[ix[0]])
+            whole += int((a != oacc[ix]).sum() + ((a == oacc[ix]) & (r != oreason[ix])).sum())
+        print(f"whole: {len(by_cfg)} one-configuration calls of {min(map(len, by_cfg.values()))}..{max(map(len, by_cfg.values()))} proofs, mismatching proofs {whole}")
+        bad += whole
     sys.exit(1 if bad else 0)
 
 
