@@ -179,6 +179,9 @@ typedef enum rsv_option {
                                      (chain layout only; not with more than 32 queries), 2 with one lane per query */
     RSV_OPT_STAGE_TIMES = 24,     /* 0 / 2 off; 1 record a HIP event pair around every stage of a verify call, which is what
                                      rsv_last_stage_times reads.  Off by default: the records cost ~8 us of queue time per stage */
+    RSV_OPT_CAP_MID = 26,         /* with the cap's top in kernels of its own (RSV_OPT_CAP_TOP): 0 auto — a bucket of proofs whose dense cap levels
+                                     fill the tree kernels' waves badly (80, 27, 11, 10 queries) hands its nodes over at the cap level, a
+                                     lane per subtree walks the middle levels (k_cap_mid), k_cap_top the rest; 1 every bucket does, 2 none */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -89,8 +89,10 @@ inline void bucket_by_shape(const uint32_t* shape, uint32_t N, std::vector<Bucke
 }
 
 // One (bucket, slot range) of a group: cn slots of bucket bi from slot c0 on, launched with G lanes per proof, the dense
-// top-of-tree cap from level Lc down, its last Lt levels in k_cap_top (0: inside the tree kernels).
-struct Entry { size_t bi; size_t c0; uint32_t cn, G, Lc, Lt; size_t bytes; };
+// top-of-tree cap from level Lc down.  Lt: the level at which the tree kernels hand their nodes over to the cap kernels
+// (0: the whole cap inside the tree kernels); Lt2 <= Lt: the level from which k_cap_top (one lane per tree) walks to the
+// root; the levels between Lt and Lt2 belong to k_cap_mid (one lane per subtree).
+struct Entry { size_t bi; size_t c0; uint32_t cn, G, Lc, Lt, Lt2; size_t bytes; };
 
 struct GroupPolicy {
     size_t budget;         // bytes of per-query workspace a group may use
@@ -99,21 +101,55 @@ struct GroupPolicy {
     bool flow;             // the pass writes PoseidonFlow records
     bool flow_cap_off;     // RSV_OPT_FLOW_CAP = 2
     bool cap_top;          // the last levels of the cap in k_cap_top
+    int cap_mid = 0;       // RSV_OPT_CAP_MID: 0 by the fill of the in-kernel cap levels, 1 hand over at the cap level wherever the cap kernels can take it, 2 never
 };
 
+// lanes per proof of a bucket's launches: tiny query counts are padded so that a workgroup holds at most 64 proofs
+inline uint32_t padded_lanes(const Bucket& b) { return b.G < 4 ? 4u : b.G; }
+
+// Cap levels of a bucket.  Lc: 2^Lc <= G, strictly below every tree's lowest leaf / data level (0: no cap).  Inside the
+// tree kernels a cap level l keeps (proofs per workgroup) x 2^l lanes busy, each part-filled wave at the price of a full
+// wave-level permutation: 16-query proofs (16 per workgroup) fill whole waves at levels 3 and 2 and leave only the last
+// two levels to k_cap_top (Lt = Lt2 = 2); three 80-query proofs put 96, 48 and 24 lanes into 2 + 1 + 1 waves (256 slots
+// for 168 nodes), nine 27-query proofs 72 and 36 lanes into 2 + 1 waves, 25 ten-query proofs 100 lanes into 2.  Such a
+// bucket hands its level-Lc nodes over (Lt = Lc) and the cap kernels, whose lanes are dealt over the whole launch, take
+// it from there: k_cap_mid a subtree per lane down to level Lt2, k_cap_top the rest (k_merkle.hpp).
+inline void cap_levels(const Bucket& b, const GroupPolicy& pol, uint32_t block, uint32_t& Lc, uint32_t& Lt, uint32_t& Lt2) {
+    const uint32_t G = padded_lanes(b);
+    Lc = 0;
+    while ((2u << Lc) <= G) Lc++;
+    if (b.minLevel < 2) Lc = 0;
+    else if (Lc > b.minLevel - 1) Lc = b.minLevel - 1;
+    if (Lc > 6) Lc = 6;
+    if (Lc < 2) Lc = 0;
+    if (pol.tree_cap_off) Lc = 0;
+    if (pol.flow && pol.flow_cap_off) Lc = 0;  // every lane walks (and records) its whole path
+    Lt = Lt2 = (pol.cap_top && !pol.flow && Lc >= 3) ? (Lc >= 6 ? 3u : 2u) : 0u;  // the cap kernels write no records
+    if (!Lt || pol.cap_mid == 2) return;
+    // wave slots of the in-kernel cap levels against the nodes they hold
+    const uint32_t pb = std::min<uint32_t>(block / G, 64u);
+    uint32_t slots = 0, nodes = 0;
+    for (uint32_t l = Lt; l < Lc; l++) { slots += ((pb << l) + 63u) / 64u * 64u; nodes += pb << l; }
+    if (pol.cap_mid == 1 || slots * 100u > nodes * 115u) {
+        Lt = Lc;
+        Lt2 = Lc <= 3 ? Lc : (Lc >= 6 ? 3u : 2u);  // k_cap_top holds 2^Lt2 <= 8 nodes in registers; k_cap_mid walks Lt - Lt2 <= 3 levels
+    }
+}
+
 // per-query workspace of cn slots of a bucket (what verify_impl carves for one Entry)
-inline size_t entry_bytes(const Bucket& b, uint32_t G, size_t cn, uint32_t Lt) {
+inline size_t entry_bytes(const Bucket& b, uint32_t G, size_t cn, uint32_t Lt, uint32_t Lt2) {
     Carve probe{nullptr};
     probe.take<PlanHdr>(cn);
     probe.take<uint32_t>(cn * (b.maxM + 1) * G);
     probe.take<uint32_t>(cn * 2 * G);
     probe.take<uint32_t>(cn * (3 + b.maxInner) * G * 8);
-    if (Lt) {
-        probe.take<uint32_t>((cn * 4 << Lt) * 8);
-        probe.take<uint32_t>(cn * 4);
-        probe.take<uint32_t>((cn * (1 + b.maxInner) << Lt) * 8);
-        probe.take<uint32_t>(cn * (1 + b.maxInner));
-    }
+    for (uint32_t L : {Lt, Lt2 != Lt ? Lt2 : 0u})
+        if (L) {
+            probe.take<uint32_t>((cn * 4 << L) * 8);
+            probe.take<unsigned long long>(cn * 4);
+            probe.take<uint32_t>((cn * (1 + b.maxInner) << L) * 8);
+            probe.take<unsigned long long>(cn * (1 + b.maxInner));
+        }
     return ((probe.off + 255) & ~(size_t)255) + 256;
 }
 
@@ -130,18 +166,10 @@ inline size_t plan_groups(const std::vector<Bucket>& buckets, const GroupPolicy&
     for (size_t bk = buckets.size(); bk-- > 0;) {
         const size_t bi = bk;
         const Bucket& b = buckets[bi];
-        const uint32_t G = b.G < 4 ? 4u : b.G;  // pad tiny query counts so that a workgroup holds at most 64 proofs
-        // cap level: 2^Lc <= G and Lc strictly below every tree's lowest leaf / data level
-        uint32_t Lc = 0;
-        while ((2u << Lc) <= G) Lc++;
-        if (b.minLevel < 2) Lc = 0;
-        else if (Lc > b.minLevel - 1) Lc = b.minLevel - 1;
-        if (Lc > 6) Lc = 6;
-        if (Lc < 2) Lc = 0;
-        if (pol.tree_cap_off) Lc = 0;
-        if (pol.flow && pol.flow_cap_off) Lc = 0;  // every lane walks (and records) its whole path
-        const uint32_t Lt = (pol.cap_top && !pol.flow && Lc >= 3) ? (Lc >= 6 ? 3u : 2u) : 0u;  // k_cap_top writes no records
-        const size_t per_slot = entry_bytes(b, G, 1024, Lt) / 1024 + 1;
+        const uint32_t G = padded_lanes(b);
+        uint32_t Lc, Lt, Lt2;
+        cap_levels(b, pol, 256u, Lc, Lt, Lt2);
+        const size_t per_slot = entry_bytes(b, G, 1024, Lt, Lt2) / 1024 + 1;
         for (size_t c0 = 0; c0 < b.count;) {
             size_t room = pol.budget > used ? (pol.budget - used) / per_slot : 0;
             size_t cn = std::min<size_t>(b.count - c0, room);
@@ -149,7 +177,7 @@ inline size_t plan_groups(const std::vector<Bucket>& buckets, const GroupPolicy&
                 if (!cur.empty()) { flush(); continue; }
                 cn = std::min<size_t>(b.count - c0, 1024);       // a budget below 1 024 slots: take them anyway
             }
-            Entry en{bi, c0, (uint32_t)cn, G, Lc, Lt, entry_bytes(b, G, cn, Lt)};
+            Entry en{bi, c0, (uint32_t)cn, G, Lc, Lt, Lt2, entry_bytes(b, G, cn, Lt, Lt2)};
             cur.push_back(en);
             used += en.bytes;
             c0 += cn;

@@ -35,11 +35,13 @@ template <int PACE = 1>
 __global__ __launch_bounds__(256) void k_row_hash(Fused<RowHashArgs> f) {
     RSV_TAG(2);
     RSV_FUSED_SELECT(f, a, bx);
-    const uint32_t G = a.G, per_block = 256 / G;
-    const uint32_t grp = threadIdx.x / G, r = threadIdx.x % G;
-    const uint32_t slot = bx * per_block + grp;
+    // rows are independent: the lanes are dealt over (slot, row) without regard to workgroup boundaries, so a query count
+    // that does not divide 256 (80, 27, 11, 10) leaves no lane idle but the launch's last ones
+    const uint32_t G = a.G;
+    const uint64_t item = (uint64_t)bx * 256 + threadIdx.x;
+    const uint32_t slot = (uint32_t)(item / G), r = (uint32_t)(item % G);
     const int t = blockIdx.y;
-    if (grp >= per_block || slot >= a.n) return;
+    if (slot >= a.n) return;
     const uint32_t p = a.ids ? a.ids[slot] : slot;
     const ProofMeta& m = a.metas[p];
     if (m.reason != R_OK || r >= m.nq) return;
@@ -95,11 +97,16 @@ struct MerkleArgs {
     //   pair_cols[(((slot*(1+maxInner) + s)*G + i)*3 + c]     c-th data level from the top: self | sibling value, 8 words
     uint32_t* pair_sib;
     uint32_t* pair_cols;
-    // top of the cap in a kernel of its own (k_cap_top): the in-kernel cap stops at level Lt (0 = it walks to the root) and
-    // leaves, per (slot, tree), the present nodes of that level and their presence mask:
+    // top of the cap in kernels of its own: the in-kernel cap stops at level Lt (0 = it walks to the root; Lt = Lc: it only
+    // hands the level-Lc nodes over) and leaves, per (slot, tree), the present nodes of that level and their presence mask:
     //   capn[((slot * T + tree) << Lt) + pos][8], capm[slot * T + tree]    T = 4 (trace trees: t*) / 1 + maxInner (FRI trees: p*)
-    uint32_t Lt;
-    uint32_t *tcapn, *tcapm, *pcapn, *pcapm;
+    // Lt2 < Lt: k_cap_mid walks from level Lt to level Lt2 (a subtree per lane) and leaves capn2 / capm2 in the same layout for
+    // k_cap_top; Lt2 == Lt: k_cap_top reads capn / capm itself (host_logic.hpp: cap_levels).
+    uint32_t Lt, Lt2;
+    uint32_t *tcapn, *pcapn;
+    unsigned long long *tcapm, *pcapm;
+    uint32_t *tcapn2, *pcapn2;
+    unsigned long long *tcapm2, *pcapm2;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -131,7 +138,7 @@ template <int BLOCK, bool FLOW = false, int PACE = 1>
 __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned long long (*mask)[64], CapGroup* grp_desc,
                                            uint32_t Lc, uint32_t per_block, bool live, uint32_t grp, uint32_t pos,
                                            const Hash8& cur, uint32_t* emit = nullptr, uint32_t emit_top = 0, uint32_t Lt = 0,
-                                           uint32_t* capn = nullptr, uint32_t* capm = nullptr, uint32_t slot0 = 0, uint32_t n_slots = 0,
+                                           uint32_t* capn = nullptr, unsigned long long* capm = nullptr, uint32_t slot0 = 0, uint32_t n_slots = 0,
                                            uint32_t T = 0, uint32_t ti = 0, const uint32_t (*fl)[FLOW ? BLOCK : 1] = nullptr, uint32_t G = 0) {
     const uint32_t t = vlane<PACE>();
     __syncthreads();  // xch is free, descriptors written
@@ -214,11 +221,11 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
         bufi ^= 1;
         __syncthreads();
     }
-    if (Lt && ti < T) {  // the levels above Lt belong to k_cap_top: hand over this level's nodes (xch[bufi], mask[bufi]);
+    if (Lt && ti < T) {  // the levels above Lt belong to the cap kernels: hand over this level's nodes (xch[bufi], mask[bufi]);
                          // ti >= T: a launch's grid covers the deepest bucket's FRI layers, this bucket has fewer trees
         const uint32_t g2 = t >> Lt, pp = t & ((1u << Lt) - 1u);
         if (g2 < per_block && slot0 + g2 < n_slots) {
-            const uint32_t cm = grp_desc[g2].active ? (uint32_t)mask[bufi][g2] : 0u;
+            const unsigned long long cm = grp_desc[g2].active ? mask[bufi][g2] : 0ull;
             const size_t idx = (size_t)(slot0 + g2) * T + ti;
             if (pp == 0) capm[idx] = cm;
             if ((cm >> pp) & 1u) store_hash(capn + ((idx << Lt) + pp) * 8, load_hash(&xch[bufi][(g2 << Lt) + pp][0]));
@@ -627,9 +634,10 @@ template <int LT, int PACE = 1>
 __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_, uint32_t ti, bool pair) {
     const uint32_t T = pair ? 1u + a.maxInner : 4u;
     const size_t idx = (size_t)slot_ * T + ti;
-    uint32_t mask = (pair ? a.pcapm : a.tcapm)[idx];
+    const bool mid = a.Lt2 != a.Lt;  // this level's nodes come from k_cap_mid
+    uint32_t mask = (uint32_t)(mid ? (pair ? a.pcapm2 : a.tcapm2) : (pair ? a.pcapm : a.tcapm))[idx];
     if (!mask) return;  // a rejected proof, or a tree this proof does not have
-    const uint32_t* capn = (pair ? a.pcapn : a.tcapn) + (idx << LT) * 8;
+    const uint32_t* capn = (mid ? (pair ? a.pcapn2 : a.tcapn2) : (pair ? a.pcapn : a.tcapn)) + (idx << LT) * 8;
     const uint32_t p = a.pl.proof_of(slot_);
     const ProofMeta& m = a.metas[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
@@ -692,9 +700,112 @@ __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopInde
     const uint32_t T = pair ? 1u + a.maxInner : 4u;
     const uint64_t item = (uint64_t)(blockIdx.x - ix.first_block[k]) * 256 + threadIdx.x;
     if (!a.Lt || item >= (uint64_t)a.n * T) return;
-    const uint32_t slot_ = (uint32_t)(item / T), ti = (uint32_t)(item % T);
-    if (a.Lt == 2) cap_top_walk<2, PACE>(a, slot_, ti, pair != 0);
+    // tree-major: a launch under one configuration is sized for the deepest trees the parser admits, and the lanes of the
+    // FRI layers no proof of the batch has leave as whole waves
+    const uint32_t ti = (uint32_t)(item / a.n), slot_ = (uint32_t)(item % a.n);
+    if (a.Lt2 == 2) cap_top_walk<2, PACE>(a, slot_, ti, pair != 0);
     else cap_top_walk<3, PACE>(a, slot_, ti, pair != 0);
+}
+
+// ---------------------------------------------------------------- k_cap_mid
+// The cap levels between the tree kernels' hand-over (level Lt = Lc) and k_cap_top's (level Lt2), ONE LANE PER
+// (slot, tree, level-Lt2 position): the lane owns the subtree below its position — 2^LA nodes of level Lt in registers,
+// 2^LA - 1 sequential node hashes — and leaves the subtree's root in capn2.  For buckets whose in-kernel cap levels fill
+// their waves badly (three 80-query proofs per workgroup: 96, 48, 24 lanes in 2 + 1 + 1 waves): here the lanes are dealt
+// over the whole launch, every wave full.  Witness ranks count the lacking parents of the WHOLE level (as merkle_cap: the
+// batched order of components/hints/src/decommit.rs:91-139), so every lane carries the level's presence mask along.
+__device__ __forceinline__ unsigned long long cap_parent_mask(unsigned long long cm) {  // bit p = bit 2p | bit 2p + 1
+    unsigned long long t = (cm | (cm >> 1)) & 0x5555555555555555ull;
+    t = (t | (t >> 1)) & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+    t = (t | (t >> 8)) & 0x0000ffff0000ffffull;
+    t = (t | (t >> 16)) & 0x00000000ffffffffull;
+    return t;
+}
+
+template <int LA, int PACE = 1>
+__device__ __forceinline__ void cap_mid_walk(const MerkleArgs& a, uint32_t slot_, uint32_t ti, uint32_t sub, bool pair) {
+    const uint32_t T = pair ? 1u + a.maxInner : 4u;
+    const size_t idx = (size_t)slot_ * T + ti;
+    unsigned long long cm = (pair ? a.pcapm : a.tcapm)[idx];  // presence at level Lt
+    unsigned long long* capm2 = (pair ? a.pcapm2 : a.tcapm2) + idx;
+    if (!cm) {  // a rejected proof, or a tree this proof does not have
+        if (sub == 0) *capm2 = 0ull;
+        return;
+    }
+    const uint32_t Lt = a.Lt, Lt2 = a.Lt2;
+    const uint32_t* capn = (pair ? a.pcapn : a.tcapn) + (idx << Lt) * 8;
+    const uint32_t p = a.pl.proof_of(slot_);
+    const ProofMeta& m = a.metas[p];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.blob + a.offsets[p]);
+    const PlanHdr& h = a.pl.hdr[slot_];
+    const uint32_t* hw;
+    const uint16_t* wf = nullptr;
+    uint32_t hw_n, s_top, fail_bit;
+    if (pair) {
+        const FriLayerRef& L = ti == 0 ? m.first : m.inner[ti - 1];
+        const uint32_t top = ti == 0 ? m.M : m.M - ti;
+        hw = w + L.hash_off; hw_n = L.hash_n; wf = ti == 0 ? h.wf : nullptr; s_top = lvl_s(h.lvl[top]);
+        fail_bit = ti == 0 ? R_FRI_FIRST : R_FRI_INNER;
+    } else {
+        const uint32_t mx = (ti == 3) ? m.M : umax(m.A, m.B);
+        hw = w + m.hw_off[ti]; hw_n = m.hw_n[ti]; s_top = lvl_s(h.lvl[mx + 1]);
+        fail_bit = R_MERKLE_T0 + ti;
+    }
+    uint32_t* flags = &a.ctxs[p].flags;
+    const uint32_t first = sub << LA;  // this subtree's first position at level Lt
+    const bool any = ((cm >> first) & ((1ull << (1 << LA)) - 1ull)) != 0ull;
+    Hash8 node[1 << LA];
+#pragma unroll
+    for (int k = 0; k < (1 << LA); k++) node[k] = ((cm >> (first + k)) & 1ull) ? load_hash(capn + 8 * (first + k)) : zero8();
+#pragma unroll
+    for (int s = LA - 1; s >= 0; s--) {  // the subtree has 2^s parents at level l = Lt2 + s; cm = presence at child level l + 1
+        const uint32_t l = Lt2 + (uint32_t)s;
+        const unsigned long long lack = (cm ^ (cm >> 1)) & 0x5555555555555555ull;  // bit 2p': exactly one child present
+        const uint32_t base = wf ? (uint32_t)wf[l + 1] : lvl_s(h.lvl[l + 2]) - s_top;
+        if (any) {
+#pragma unroll
+            for (int pp = 0; pp < (1 << s); pp++) {
+                const uint32_t gp = (sub << s) + (uint32_t)pp;  // parent position in its level
+                const uint32_t pres = (uint32_t)(cm >> (2 * gp)) & 3u;
+                if (pres) {
+                    Hash8 left = node[2 * pp], right = node[2 * pp + 1];
+                    if (pres != 3u) {
+                        const uint32_t wi = base + (uint32_t)__popcll(lack & ((1ull << (2 * gp)) - 1ull));
+                        Hash8 w8 = zero8();
+                        if (wi < hw_n) {
+                            w8 = load_hash(hw + 8 * wi);
+                            if (hash_over(w8)) atomicOr(flags, 1u << R_PARSE);
+                        } else atomicOr(flags, (1u << fail_bit) | F_RESCAN);
+                        if (!(pres & 1u)) left = w8;
+                        if (!(pres & 2u)) right = w8;
+                    }
+                    node[pp] = hash_tree<PACE>(left, right);
+                }
+            }
+        }
+        cm = cap_parent_mask(cm);
+    }
+    if (sub == 0) *capm2 = cm;
+    if (any) store_hash((pair ? a.pcapn2 : a.tcapn2) + ((idx << Lt2) + sub) * 8, node[0]);
+}
+
+template <int PACE = 1>
+__global__ __launch_bounds__(256) void k_cap_mid(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
+    RSV_TAG(pair ? 4 : 3);
+    uint32_t k = 0;
+    while (k + 1 < f.nb && blockIdx.x >= ix.first_block[k + 1]) k++;
+    const MerkleArgs& a = f.a[k];
+    if (a.Lt2 == a.Lt) return;  // (such an argument set has no blocks here)
+    const uint32_t T = pair ? 1u + a.maxInner : 4u;
+    const uint64_t item = (uint64_t)(blockIdx.x - ix.first_block[k]) * 256 + threadIdx.x;
+    if (item >= ((uint64_t)a.n * T << a.Lt2)) return;
+    const uint32_t sub = (uint32_t)(item & ((1u << a.Lt2) - 1u));
+    const uint64_t tree = item >> a.Lt2;
+    const uint32_t ti = (uint32_t)(tree / a.n), slot_ = (uint32_t)(tree % a.n);  // tree-major, as k_cap_top
+    if (a.Lt - a.Lt2 == 2) cap_mid_walk<2, PACE>(a, slot_, ti, sub, pair != 0);
+    else cap_mid_walk<3, PACE>(a, slot_, ti, sub, pair != 0);
 }
 
 }  // namespace rsv

@@ -185,7 +185,7 @@ static void check_buckets(const std::vector<uint32_t>& shape, uint32_t N, size_t
     CHECK(at == live);
     // groups: every slot of every bucket in exactly one entry; a group within the budget unless it is a single minimum entry
     std::vector<std::vector<host::Entry>> groups;
-    const host::GroupPolicy pol{budget, max_fused, false, false, false, cap_top};
+    const host::GroupPolicy pol{budget, max_fused, false, false, false, cap_top, (int)((N + budget) % 3)};  // RSV_OPT_CAP_MID: all three settings over the runs
     const size_t need = host::plan_groups(buckets, pol, groups);
     std::vector<size_t> covered(buckets.size(), 0);
     size_t worst = 0;
@@ -194,8 +194,8 @@ static void check_buckets(const std::vector<uint32_t>& shape, uint32_t N, size_t
         size_t used = 0;
         for (const host::Entry& e : g) {
             CHECK(e.bi < buckets.size() && e.c0 == covered[e.bi] && e.cn > 0 && e.c0 + e.cn <= buckets[e.bi].count);
-            CHECK(e.G >= 4 && e.G >= buckets[e.bi].G && e.Lc <= 6 && e.Lt <= 3 && (e.Lt == 0 || e.Lc >= 3));
-            CHECK(e.bytes == host::entry_bytes(buckets[e.bi], e.G, e.cn, e.Lt));
+            CHECK(e.G >= 4 && e.G >= buckets[e.bi].G && e.Lc <= 6 && e.Lt <= e.Lc && e.Lt2 <= 3 && e.Lt2 <= e.Lt && e.Lt - e.Lt2 <= 3 && (e.Lt - e.Lt2 != 1) && (e.Lt == 0 || (e.Lc >= 3 && e.Lt2 >= 2)));
+            CHECK(e.bytes == host::entry_bytes(buckets[e.bi], e.G, e.cn, e.Lt, e.Lt2));
             covered[e.bi] += e.cn;
             used += e.bytes;
         }

@@ -37,7 +37,7 @@ def main():
             per = counter()
             lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)
             print("   " + ", ".join(f"{TAGS[t]} {per[t][0] / n:.1f} lanes / {per[t][1] * 64 / n:.1f} slots" for t in TAGS if per[t][1]))
-            print(f"{name}: oracle (batched walk) {want} perms/proof; GPU cap={env}: {lanes / n:.1f} lane-perms/proof "
+            print(f"{name} cap_mid={mid}: oracle (batched walk) {want} perms/proof; GPU cap={env}: {lanes / n:.1f} lane-perms/proof "
                   f"({lanes / n / want:.3f}x), {waves * 64 / n:.1f} wave-slot perms/proof ({waves * 64 / n / want:.3f}x)")
 
 
@@ -61,6 +61,32 @@ def mixed():
               f"{waves * 64 / n:.1f} wave-slot perms ({waves * 64 / n / want:.3f}x)")
 
 
+def chain_shapes():
+    """every shape of the recursion chain, one configuration per call (paced lane-form trees, as a large batch runs them)"""
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level5-1.bin", "level7-1.bin", "level8-1.bin", "level9-1.bin", "level10-1.bin", "level12-1.bin", "level13-1.bin"]
+    rsv.set_default_option("tree_cap", "on")
+    rsv.set_default_option("transcript_form", "lane")
+    rsv.set_default_option("tree_pace", "paced")
+    for name in names:
+        proof = open(os.path.join(ROOT, "tests", "golden", "proofs", name), "rb").read()
+        want = ob.perm_count(proof)
+        n = 3840
+        for mid in ("off", "auto"):
+            rsv.set_default_option("cap_mid", mid)
+            counter()
+            acc, _ = rsv.verify_batch([proof] * n, ob.header_cfg(proof))
+            assert acc.all()
+            per = counter()
+            lanes, waves = sum(a for a, _ in per), sum(b for _, b in per)
+            print(f"{name} cap_mid={mid}: oracle {want}; lanes {lanes / n:.1f} ({lanes / n / want:.3f}x), slots {waves * 64 / n:.1f} ({waves * 64 / n / want:.3f}x)  "
+                  + ", ".join(f"{TAGS[t][2:]} {per[t][0] / n:.0f}/{per[t][1] * 64 / n:.0f}" for t in TAGS if per[t][1]))
+    rsv.set_default_option("tree_pace", 0)
+    rsv.set_default_option("cap_mid", 0)
+
+
 if __name__ == "__main__":
     mixed()
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":
+        chain_shapes()
+    else:
+        main()

@@ -569,6 +569,36 @@ def test_tree_kernel_forms_match_oracle(rsv, knobs, pace, order):
     assert acc3.tolist() == o1.tolist() and reason3.tolist() == r1.tolist()
 
 
+@pytest.mark.parametrize("mid", ["auto", "on", "off"])
+@pytest.mark.parametrize("pace", ["paced", "unpaced"])
+def test_cap_mid_forms_match_oracle(rsv, knobs, mid, pace):
+    """The top of every Merkle tree with the cap kernels (production: batches of >= 1 024 proofs): a bucket hands its nodes over
+    at the cap level and k_cap_mid (a lane per subtree) + k_cap_top finish the tree — for the query counts whose dense cap
+    levels fill the tree kernels' waves badly (auto: 80, 27, 11, 10), for every bucket (on), for none (off).  Every shape of
+    the recursion chain with tampered copies, several proofs per workgroup and a ragged last one, then one configuration
+    per call (the device-side slot order): verdicts and reasons == the oracle's."""
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+             "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]
+    knobs.set("tree_pace", pace)
+    knobs.set("cap_top", "on")
+    knobs.set("cap_mid", mid)
+    batch, cfgs = [], []
+    for k in range(13 * 7 + 5):
+        nm = names[k % 13]
+        pr = read_proof(nm)
+        batch.append(ob.tamper(pr, k) if k % 4 == 1 else pr)
+        cfgs.append(fixture_cfg(nm))
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist() and 40 < int(acc.sum()) < 90
+    for nm, n in (("level1-5.bin", 7), ("level2-1.bin", 19), ("level10-1.bin", 53), ("recursive_proof_16_15.bin", 35), ("level13-1.bin", 70)):
+        pr = read_proof(nm)
+        one = [ob.tamper(pr, 5 * k) if k % 3 == 2 else pr for k in range(n)]
+        a1, r1 = rsv.verify_batch(one, fixture_cfg(nm))
+        o1, q1 = ob.verify_batch(one, fixture_cfg(nm))
+        assert a1.tolist() == o1.tolist() and r1.tolist() == q1.tolist() and int(a1.sum()) >= n // 2, nm
+
+
 @pytest.mark.parametrize("trees", ["paced", "row16"])
 @pytest.mark.parametrize("name", ["small_proof.bin", "recursive_proof_16_15.bin", "level2-1.bin", "level13-1.bin"])
 def test_trace_paths_match_oracle(rsv, manifest, knobs, name, trees):
