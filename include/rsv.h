@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RSV_M31_P 0x7fffffffu
-#define RSV_ABI_VERSION 5
+#define RSV_ABI_VERSION 6
 
 typedef enum rsv_status {
     RSV_OK = 0,
@@ -45,7 +45,8 @@ typedef enum rsv_status {
     RSV_E_DEVICE = -3,   /* no such HIP device, or a HIP call failed */
     RSV_E_CAP = -4,      /* output capacity too small */
     RSV_E_RANGE = -5,    /* input word not a canonical M31 */
-    RSV_E_UNAVAILABLE = -6 /* an optional run-time dependency (RCCL, for rsv_exchange_*) could not be loaded */
+    RSV_E_UNAVAILABLE = -6, /* an optional run-time dependency (RCCL, for rsv_exchange_*) could not be loaded */
+    RSV_E_NOMEM = -7     /* host memory for the call's staging could not be allocated (no verdict was written) */
 } rsv_status;
 
 /* Why proof i was rejected.  Order = the order in which the reference's
@@ -64,7 +65,8 @@ typedef enum rsv_status {
  * nonce and the proof's final word, last_layer_poly.log_size. */
 typedef enum rsv_reason {
     RSV_R_OK = 0,
-    RSV_R_PARSE = 1,        /* bincode shape / config mismatch (examples/single-proof/src/main.rs:24-31) */
+    RSV_R_PARSE = 1,        /* bincode shape / config mismatch (examples/single-proof/src/main.rs:24-31), a non-canonical field
+                               element, or a header beyond this library's shape limits (RSV_MAX_*, below) */
     RSV_R_POW = 2,          /* components/recursive/fiat_shamir/src/lib.rs:115-117 */
     RSV_R_LOGUP = 3,        /* components/recursive/fiat_shamir/src/lib.rs:133-141 */
     RSV_R_COMPOSITION = 4,  /* components/recursive/composition/src/lib.rs:106-120 */
@@ -87,6 +89,30 @@ typedef struct rsv_pcs_config {
     uint32_t log_last_layer_degree_bound;
     uint32_t n_queries;
 } rsv_pcs_config;
+
+/* SHAPE LIMITS of this library (the reference has none: its vectors grow with the proof).  Tables in HBM and LDS are
+ * sized by them.
+ *   A CONFIGURATION beyond them is refused: every entry point that takes an rsv_cfg_set returns RSV_E_SIZE (and writes
+ *   no verdict) unless every configuration of the set has
+ *       1 <= n_queries <= RSV_MAX_QUERIES,  1 <= log_blowup_factor <= RSV_MAX_LOG_BLOWUP,
+ *       log_last_layer_degree_bound <= RSV_MAX_LOG_LAST_LAYER,  pow_bits <= RSV_MAX_POW_BITS;
+ *   rsv_cfg_check tells without a device.
+ *   A PROOF whose own header goes beyond them — component log sizes (log_size_plonk, log_size_poseidon) outside
+ *   1 .. RSV_MAX_COMPONENT_LOG, or a largest column log size M = max(log_size_plonk + 1, log_size_poseidon + 2) +
+ *   log_blowup_factor above RSV_MAX_LOG_SIZE (which also bounds the FRI inner layers by RSV_MAX_FRI_INNER) — is data, not
+ *   misuse: it is rejected with RSV_R_PARSE like any proof this library cannot read, although the reference would verify
+ *   it if it is genuine.  (Every fixture of the reference: n_queries 8 .. 80, M 21 .. 28, 7 .. 12 inner layers.)
+ *   The witness entry points (rsv_witness_*) additionally need log_size_plonk, log_size_poseidon <= RSV_MAX_WITNESS_LOG. */
+#define RSV_MAX_QUERIES 128
+#define RSV_MAX_LOG_BLOWUP 16
+#define RSV_MAX_LOG_LAST_LAYER 16
+#define RSV_MAX_POW_BITS 30
+#define RSV_MAX_COMPONENT_LOG 28
+#define RSV_MAX_LOG_SIZE 30
+#define RSV_MAX_FRI_INNER 28
+#define RSV_MAX_WITNESS_LOG 24
+/* RSV_OK if the library can verify proofs under *cfg, RSV_E_SIZE if it is beyond the limits above, RSV_E_NULL. */
+int rsv_cfg_check(const rsv_pcs_config* cfg);
 
 /* The configuration(s) the caller expects — REQUIRED by every entry point that produces a verdict.  The reference
  * never takes the configuration from the proof: FiatShamirHints::new(&proof, config, ..)
@@ -182,6 +208,9 @@ typedef enum rsv_option {
     RSV_OPT_CAP_MID = 26,         /* with the cap's top in kernels of its own (RSV_OPT_CAP_TOP): 0 auto — a bucket of proofs whose dense cap levels
                                      fill the tree kernels' waves badly (80, 27, 11, 10 queries) hands its nodes over at the cap level, a
                                      lane per subtree walks the middle levels (k_cap_mid), k_cap_top the rest; 1 every bucket does, 2 none */
+    RSV_OPT_TREE_GUESTS = 27,     /* batches of several query counts, large enough for the paced Merkle kernels and the cap kernels: 0 / 1 the lanes
+                                     a workgroup's own proofs leave idle (three 80-query proofs fill 240 of 256) walk the paths of proofs
+                                     of another bucket of the launch (one 16-query proof), 2 they stay idle */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;
@@ -568,9 +597,19 @@ int rsv_accept_bitmap_dev(rsv_ctx* ctx, const uint8_t* d_accept, size_t n,
  *     exchange their bitmap slices with ONE ncclAllGather and their counts with ONE ncclAllReduce over RCCL / xGMI
  *     (rsv_exchange).  RCCL is bound at run time, never linked; RSV_E_UNAVAILABLE where it cannot be loaded.
  *
- * Shard rule (both layouts, and recursive-stwo_amd/sharding.py): rank r of `world` owns [lo, hi) with sizes differing
- * by at most one, the larger shards first. */
+ * Shard rules (both layouts, and recursive-stwo_amd/sharding.py).  Shards are contiguous index ranges, shard 0 first.
+ *   rsv_shard_range   a UNIFORM job (proofs of one shape, or shapes in round-robin order): rank r of `world` owns
+ *                     [lo, hi) with sizes differing by at most one, the larger shards first.
+ *   rsv_shard_plan    any job, balanced by WORK: bytes are the work (21 - 26.5 proof bytes per permutation over every shape
+ *                     of the reference, and the verifier is permutation-bound), so the cut between ranks r - 1 and r is
+ *                     the proof boundary nearest to r / world of the job's bytes.  The reference's own job arrives ordered
+ *                     by level (examples/multi-proofs/src/main.rs:198-295: 435 KB / 80-query proofs first, 76 KB / 8-query
+ *                     ones last): cut by count, rank 0 of 8 gets 4.5 x the bytes of rank 7; cut by bytes, every rank the
+ *                     same within one proof.  lens: n proof lengths (HOST); lo, hi: `world` entries each (HOST, written);
+ *                     world in 1 .. 4096 (RSV_E_SIZE).  Deterministic: every rank computes the same plan from the same
+ *                     lengths.  rsv_multi_verify_batch_host cuts its job this way. */
 void rsv_shard_range(size_t n_total, size_t rank, size_t world, size_t* lo, size_t* hi);
+int rsv_shard_plan(const uint64_t* lens, size_t n, size_t world, size_t* lo, size_t* hi);
 
 typedef struct rsv_multi rsv_multi;
 /* n_devices in 1 .. 64; every entry a valid HIP device index (RSV_E_DEVICE otherwise). */
@@ -583,7 +622,8 @@ rsv_ctx* rsv_multi_ctx(rsv_multi* m, size_t rank);
  * rsv_verify_batch_host on shard rsv_shard_range(n, r, size) from its own thread (gather -> pinned -> DMA -> verify,
  * pipelined per device).  accept / reason: n bytes each (reason may be NULL); bitmap: ceil(n / 32) little-endian words
  * (bit i = accept[i]) or NULL; count: accepted proofs or NULL.  cfg->cfg_of (HOST memory here) indexes the whole job.
- * Blocks until every verdict is written.  The first failing rank's status is returned. */
+ * Blocks until every verdict is written.  The first failing rank's status is returned (RSV_E_NOMEM: a rank could not
+ * allocate its host staging). */
 int rsv_multi_verify_batch_host(rsv_multi* m, const uint8_t* const* proofs, const uint64_t* lens, size_t n,
                                 const rsv_cfg_set* cfg, const rsv_public_input* pi, size_t n_pi, uint8_t* accept,
                                 uint8_t* reason, uint32_t* bitmap, uint64_t* count);
@@ -605,25 +645,36 @@ typedef struct rsv_shard {
 int rsv_multi_verify_batch_dev(rsv_multi* m, const rsv_shard* shards, size_t n_shards, const rsv_cfg_set* cfg,
                                const rsv_public_input* pi, size_t n_pi, uint32_t* bitmap, uint64_t* count);
 
-/* Layout (2).  rank 0 obtains an id (ncclGetUniqueId) and hands its RSV_EXCHANGE_ID_BYTES bytes to the other ranks by
+/* Layout (2).  TESTED ON ONE DEVICE ONLY so far (world 1 on hardware, world 2 / 3 / 8 over gloo on CPUs: this pool has
+ * one-GPU boxes).  rank 0 obtains an id (ncclGetUniqueId) and hands its RSV_EXCHANGE_ID_BYTES bytes to the other ranks by
  * whatever channel the host has (a file, an environment variable, MPI, a torch store); every rank then calls
  * rsv_exchange_create — collectively: it returns when all `world` ranks have joined (ncclCommInitRank on ctx's device).
- * Per batch: verify the shard with rsv_verify_hints_dev asking for d_accept_bitmap = d_local (slice_words words, the
- * library zeroes the bits above the shard) and d_accept_count = d_count, then rsv_exchange_run — enqueued on ctx's
- * stream behind the verifying pass, no host synchronisation: afterwards d_gathered [world][slice_words] holds every
- * rank's slice and *d_count the job's total on every rank.  rsv_exchange_assemble (pure host arithmetic, no RCCL
- * needed) turns a host copy of d_gathered into the job's accept bytes and / or contiguous bitmap. */
+ * Per batch: verify the shard with rsv_verify_hints_dev asking for d_accept_bitmap = d_local (a buffer of slice_words
+ * words; the verifying pass writes ceil(shard / 32) of them with the bits above the shard zero) and d_accept_count =
+ * d_count, then rsv_exchange_run — enqueued on ctx's stream behind the verifying pass, no host synchronisation: it zeroes
+ * the words of d_local above the shard's own (a narrower shard than the widest sends slice_words words all the same),
+ * afterwards d_gathered [world][slice_words] holds every rank's slice — nothing but accept bits and zeros — and *d_count
+ * the job's total on every rank.  rsv_exchange_assemble (pure host arithmetic, no RCCL needed) turns a host copy of
+ * d_gathered into the job's accept bytes and / or contiguous bitmap.
+ * rsv_exchange_create cuts the job with rsv_shard_range; rsv_exchange_create_plan / rsv_exchange_assemble_plan take the
+ * cuts of every rank (lo, hi: `world` entries each, contiguous from 0 — rsv_shard_plan's, or the caller's own;
+ * RSV_E_SIZE otherwise), slice_words is then the widest shard's.
+ * Lifetime: destroy an exchange BEFORE the context it was created on (it enqueues on that context's stream). */
 #define RSV_EXCHANGE_ID_BYTES 128
 typedef struct rsv_exchange rsv_exchange;
 int rsv_exchange_available(void);     /* 1 if RCCL could be bound in this process, else 0 */
 int rsv_exchange_rccl_version(void);  /* ncclGetVersion, 0 if unavailable */
 int rsv_exchange_unique_id(uint8_t* id128);
 int rsv_exchange_create(rsv_ctx* ctx, const uint8_t* id128, int rank, int world, size_t n_total, rsv_exchange** out);
+int rsv_exchange_create_plan(rsv_ctx* ctx, const uint8_t* id128, int rank, int world, const size_t* lo, const size_t* hi,
+                             rsv_exchange** out);
 void rsv_exchange_destroy(rsv_exchange* x);
 /* This rank's [lo, hi) and the slice size every rank contributes (the largest shard's bitmap words, at least 1). */
 int rsv_exchange_layout(const rsv_exchange* x, size_t* lo, size_t* hi, size_t* slice_words);
-int rsv_exchange_run(rsv_exchange* x, const uint32_t* d_local, uint32_t* d_gathered, uint64_t* d_count);
+int rsv_exchange_run(rsv_exchange* x, uint32_t* d_local, uint32_t* d_gathered, uint64_t* d_count);
 int rsv_exchange_assemble(size_t n_total, size_t world, const uint32_t* gathered, uint8_t* accept, uint32_t* bitmap);
+int rsv_exchange_assemble_plan(size_t world, const size_t* lo, const size_t* hi, const uint32_t* gathered, uint8_t* accept,
+                               uint32_t* bitmap);
 
 /* Per-stage kernel time of the last rsv_verify_batch_dev on this ctx, measured
  * with HIP events on the ctx stream (ms); all zero unless RSV_OPT_STAGE_TIMES = 1 was set

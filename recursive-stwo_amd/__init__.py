@@ -19,6 +19,7 @@ Reference items mirrored (values only; see include/rsv.h for file:line):
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 from typing import Iterable, Optional, Sequence
 
@@ -212,6 +213,10 @@ def _load() -> ctypes.CDLL:
         "rsv_host_alloc": (ctypes.c_int, [sz, ctypes.POINTER(vp)]),
         "rsv_host_free": (None, [vp]),
         "rsv_shard_range": (None, [sz, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "rsv_shard_plan": (ctypes.c_int, [_u64p, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "rsv_cfg_check": (ctypes.c_int, [ctypes.POINTER(PcsConfig)]),
+        "rsv_exchange_create_plan": (ctypes.c_int, [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(vp)]),
+        "rsv_exchange_assemble_plan": (ctypes.c_int, [sz, ctypes.POINTER(sz), ctypes.POINTER(sz), _u32p, _u8p, _u32p]),
         "rsv_multi_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), sz, ctypes.POINTER(vp)]),
         "rsv_multi_destroy": (None, [vp]),
         "rsv_multi_size": (sz, [vp]),
@@ -249,7 +254,8 @@ EXPORTS = ["rsv_abi_version", "rsv_device_count", "rsv_ctx_create", "rsv_ctx_des
            "rsv_witness_scratch_bytes", "rsv_witness_eval_dev", "rsv_witness_eval",
            "rsv_host_alloc", "rsv_host_free", "rsv_shard_range", "rsv_multi_create", "rsv_multi_destroy", "rsv_multi_size", "rsv_multi_ctx", "rsv_multi_verify_batch_host",
            "rsv_multi_verify_batch_dev", "rsv_exchange_available", "rsv_exchange_rccl_version", "rsv_exchange_unique_id",
-           "rsv_exchange_create", "rsv_exchange_destroy", "rsv_exchange_layout", "rsv_exchange_run", "rsv_exchange_assemble"]
+           "rsv_exchange_create", "rsv_exchange_destroy", "rsv_exchange_layout", "rsv_exchange_run", "rsv_exchange_assemble",
+           "rsv_shard_plan", "rsv_cfg_check", "rsv_exchange_create_plan", "rsv_exchange_assemble_plan"]
 
 
 def _check(rc: int, what: str) -> None:
@@ -272,7 +278,7 @@ def device_count() -> int:
 OPTIONS = {"transcript_form": 1, "transcript_split": 2, "oods_form": 3, "qconst_form": 4, "plan_form": 5, "tree_cap": 6,
            "overlap_trees": 7, "ws_budget_mb": 8, "perm_wg_per_cu": 9, "host_chunk_mb": 10, "host_threads": 11, "debug_log": 12,
            "critical_chain": 13, "device_order": 14, "graph": 15,
-           "witness_layout": 16, "witness_small_max": 17, "witness_small_log": 18, "cap_top": 19, "witness_walk_log": 20, "flow_cap": 21, "pair_order": 22, "tree_pace": 23, "stage_times": 24, "query_form": 25, "cap_mid": 26}
+           "witness_layout": 16, "witness_small_max": 17, "witness_small_log": 18, "cap_top": 19, "witness_walk_log": 20, "flow_cap": 21, "pair_order": 22, "tree_pace": 23, "stage_times": 24, "query_form": 25, "cap_mid": 26, "tree_guests": 27}
 OPTION_VALUES = {"auto": 0, "row": 1, "lane": 2, "paced": 1, "unpaced": 2, "row16": 3, "whole": 1, "split": 2, "parallel": 1, "serial": 2, "on": 1, "off": 2, "device": 1, "host": 2,
                  "by_proof": 1, "by_variable": 2}
 
@@ -743,9 +749,15 @@ class Context:
         self._h = h
         self.device = device
         self._live = []
+        self._dependents = []  # weak references to the Exchange objects created on this context
 
     def close(self):
         if self._h:
+            for ref in self._dependents:  # an exchange enqueues on this context's stream: it goes first (rsv.h)
+                x = ref()
+                if x is not None:
+                    x.close()
+            self._dependents = []
             lib.rsv_ctx_destroy(self._h)  # waits for the context's streams
             self._h = None
             self._live = []
@@ -901,6 +913,19 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo.value, hi.value
 
 
+def shard_plan(lens, world: int):
+    """rsv_shard_plan: contiguous cuts balanced by bytes.  lens: the job's proof lengths.  Returns (lo, hi), `world` entries each."""
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    lo, hi = (ctypes.c_size_t * world)(), (ctypes.c_size_t * world)()
+    _check(lib.rsv_shard_plan(ln.ctypes.data_as(_u64p), len(ln), world, lo, hi), "rsv_shard_plan")
+    return list(lo), list(hi)
+
+
+def cfg_check(cfg: "PcsConfig") -> bool:
+    """rsv_cfg_check: is the configuration inside the library's shape limits (include/rsv.h: RSV_MAX_*)?"""
+    return lib.rsv_cfg_check(ctypes.byref(cfg)) == 0
+
+
 class MultiContext:
     """rsv_multi: ONE process drives several contexts (one per entry of `devices`; a device may repeat), one host thread
     per context per call; the job's verdicts, bitmap and count are assembled on the host (no collective)."""
@@ -973,13 +998,19 @@ def exchange_unique_id() -> bytes:
     return bytes(buf)
 
 
-def exchange_assemble(n_total: int, world: int, gathered: np.ndarray):
-    """rsv_exchange_assemble: gathered [world][slice_words] (host) -> (accept bytes, contiguous bitmap) of the job."""
+def exchange_assemble(n_total: int, world: int, gathered: np.ndarray, plan=None):
+    """rsv_exchange_assemble[_plan]: gathered [world][slice_words] (host) -> (accept bytes, contiguous bitmap) of the job.
+    plan = (lo, hi) of every rank for a job cut by rsv_shard_plan (or by the caller); None: rsv_shard_range's cuts."""
     g = np.ascontiguousarray(gathered, dtype=np.uint32)
     accept = np.zeros(max(n_total, 1), np.uint8)
     bitmap = np.zeros(max(1, (n_total + 31) // 32), np.uint32)
-    _check(lib.rsv_exchange_assemble(n_total, world, g.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), bitmap.ctypes.data_as(_u32p)),
-           "rsv_exchange_assemble")
+    if plan is None:
+        _check(lib.rsv_exchange_assemble(n_total, world, g.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), bitmap.ctypes.data_as(_u32p)),
+               "rsv_exchange_assemble")
+    else:
+        lo, hi = (ctypes.c_size_t * world)(*plan[0]), (ctypes.c_size_t * world)(*plan[1])
+        _check(lib.rsv_exchange_assemble_plan(world, lo, hi, g.ctypes.data_as(_u32p), accept.ctypes.data_as(_u8p), bitmap.ctypes.data_as(_u32p)),
+               "rsv_exchange_assemble_plan")
     return accept[:n_total], bitmap[: (n_total + 31) // 32]
 
 
@@ -987,11 +1018,18 @@ class Exchange:
     """rsv_exchange: the one-process-per-GPU collective step over RCCL, driven through the C-ABI (no torch.distributed on
     the data path).  `uid` = exchange_unique_id() of rank 0, distributed by the caller.  Collective constructor."""
 
-    def __init__(self, ctx: "Context", uid: bytes, rank: int, world: int, n_total: int):
+    def __init__(self, ctx: "Context", uid: bytes, rank: int, world: int, n_total: int, plan=None):
+        """plan = (lo, hi) of every rank (rsv_shard_plan's cuts, or the caller's): rsv_exchange_create_plan; None: the job is
+        cut by rsv_shard_range.  Close the exchange before its context (rsv.h)."""
         buf = (ctypes.c_uint8 * EXCHANGE_ID_BYTES).from_buffer_copy(uid)
         h = ctypes.c_void_p()
-        _check(lib.rsv_exchange_create(ctx._h, buf, rank, world, n_total, ctypes.byref(h)), "rsv_exchange_create")
+        if plan is None:
+            _check(lib.rsv_exchange_create(ctx._h, buf, rank, world, n_total, ctypes.byref(h)), "rsv_exchange_create")
+        else:
+            lo_a, hi_a = (ctypes.c_size_t * world)(*plan[0]), (ctypes.c_size_t * world)(*plan[1])
+            _check(lib.rsv_exchange_create_plan(ctx._h, buf, rank, world, lo_a, hi_a, ctypes.byref(h)), "rsv_exchange_create_plan")
         self._h, self.ctx, self.rank, self.world, self.n_total = h, ctx, rank, world, n_total
+        ctx._dependents.append(weakref.ref(self))
         lo, hi, sw = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         _check(lib.rsv_exchange_layout(h, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(sw)), "rsv_exchange_layout")
         self.lo, self.hi, self.slice_words = lo.value, hi.value, sw.value

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
         if (want[0] != m.pow_bits || want[1] != m.blowup || want[2] != m.log_last || want[3] != nq) return;
     }
     uint32_t b = m.blowup, last = m.log_last;
+    // the library's shape limits (include/rsv.h: RSV_MAX_*; a configuration beyond them never gets here: RSV_E_SIZE)
     if (m.lp < 1 || m.lq < 1 || m.lp > 28 || m.lq > 28 || b < 1 || b > 16 || last > 16 || m.pow_bits > 30) return;
     uint32_t A = m.lp + b, B = m.lq + b, M = umax(m.lp + 1, m.lq + 2) + b;
     if (M > MAX_LOG) return;

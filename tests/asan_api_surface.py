@@ -11,7 +11,7 @@ import rsvload
 rsv = rsvload.load_package(lib_path=sys.argv[1])
 lib = rsv.lib
 out = np.zeros(16, np.uint32)
-assert lib.rsv_abi_version() == 5
+assert lib.rsv_abi_version() == 6
 # argument validation, options, pure host entry points: no device in this container, every device call must fail cleanly
 assert lib.rsv_poseidon2_permute(None, out.ctypes.data_as(rsv._u32p), 1, 0) == -1
 assert lib.rsv_ctx_create(0, None) == -1

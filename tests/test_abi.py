@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rsv):
     lib = ctypes.CDLL(rsv.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rsv.h but not exported by librsv_hip.so"
-    assert lib.rsv_abi_version() == 5
+    assert lib.rsv_abi_version() == 6
     assert sorted(rsv.EXPORTS) == declared_functions()
 
 
