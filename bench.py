@@ -81,23 +81,50 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES):
+def job_fixture_index(i, n_fixtures, order="round_robin", n_total=None):
+    """Which fixture proof i of the job is a copy of.  round_robin: i mod F (the bench mixes).  level: the job in the order
+    the reference's driver produces it (examples/multi-proofs/src/main.rs:198-295): all copies of level 1, then level 2, ...
+    — equal counts per fixture, the last one takes the remainder."""
+    i = np.asarray(i, dtype=np.int64)
+    if order == "round_robin":
+        return i % n_fixtures
+    per = max(1, int(n_total) // n_fixtures)
+    return np.minimum(i // per, n_fixtures - 1)
+
+
+def job_lengths(n_total, fixtures, order):
+    """Byte length of every proof of the job (what rsv_shard_plan balances): every rank computes the same plan from it."""
+    lens = np.array([len(read_fixture(f)) for f in fixtures], dtype=np.uint64)
+    return lens[job_fixture_index(np.arange(n_total), len(fixtures), order, n_total)]
+
+
+def build_batch_on_device(torch, dev, n_proofs, first_index, fixtures=FIXTURES, order="round_robin", n_total=None):
     """Returns (d_blob uint8, d_offsets int64[n+1], lengths, tamper indices, fixture index per proof) for global proof
     indices [first_index, first_index + n_proofs)."""
     proofs = [read_fixture(f) for f in fixtures]
     lens = np.array([len(p) for p in proofs], dtype=np.int64)
-    idx = (np.arange(n_proofs, dtype=np.int64) + first_index) % len(proofs)
+    idx = job_fixture_index(np.arange(n_proofs, dtype=np.int64) + first_index, len(proofs), order, n_total)
     plen = lens[idx]
     offsets = np.zeros(n_proofs + 1, dtype=np.int64)
     np.cumsum(plen, out=offsets[1:])
     total = int(offsets[-1])
-    # one period (aligned to the round-robin phase) tiled across the batch, built in HBM
-    phase = int(first_index % len(proofs))
-    order = [(phase + k) % len(proofs) for k in range(len(proofs))]
-    period = np.frombuffer(b"".join(proofs[k] for k in order), dtype=np.uint8)
-    d_period = torch.from_numpy(period.copy()).to(dev)
-    reps = (n_proofs + len(proofs) - 1) // len(proofs)
-    d_blob = d_period.repeat(reps)[:total].contiguous()
+    if order == "round_robin":
+        # one period (aligned to the round-robin phase) tiled across the batch, built in HBM
+        phase = int(first_index % len(proofs))
+        seq = [(phase + k) % len(proofs) for k in range(len(proofs))]
+        period = np.frombuffer(b"".join(proofs[k] for k in seq), dtype=np.uint8)
+        d_period = torch.from_numpy(period.copy()).to(dev)
+        reps = (n_proofs + len(proofs) - 1) // len(proofs)
+        d_blob = d_period.repeat(reps)[:total].contiguous()
+    else:
+        # runs of one fixture each, built in HBM
+        cuts = np.flatnonzero(np.diff(idx)) + 1
+        starts = np.concatenate([[0], cuts, [n_proofs]])
+        parts = []
+        for a, b in zip(starts[:-1], starts[1:]):
+            if b > a:
+                parts.append(torch.from_numpy(np.frombuffer(proofs[int(idx[a])], dtype=np.uint8).copy()).to(dev).repeat(int(b - a)))
+        d_blob = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
     # seeded tampering (SURVEY §8d)
     tam = [i for i in range(n_proofs) if (first_index + i) % 17 == 5]
     pos = np.array([offsets[i] + 60 + splitmix64(0xC0FFEE, first_index + i) % (int(plen[i]) - 68) for i in tam],
@@ -236,6 +263,17 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="oracle sample size (0 = skip, -1 = auto)")
     ap.add_argument("--perm-log2", type=int, default=24, help="Poseidon2 microbench size (log2 states, 0 = skip)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="standard")
+    ap.add_argument("--order", choices=["round_robin", "level"], default="round_robin",
+                    help="how the job's proofs are ordered: round-robin over the workload's fixtures (the bench line), or level by "
+                         "level as the reference's driver produces a recursion chain (examples/multi-proofs/src/main.rs:198-295). "
+                         "With --total-proofs the job is cut by rsv_shard_plan (contiguous, balanced by bytes) either way.")
+    ap.add_argument("--exchange", choices=["torch", "c"], default="torch",
+                    help="the per-step exchange of accept bitmaps: torch.distributed collectives (default: the path the multi-rank "
+                         "tests rehearse) or the C-ABI's own (rsv_exchange_*: ncclAllGather + ncclAllReduce issued by the library "
+                         "on the verifier's stream, what a Rust host would call)")
+    ap.add_argument("--devices", default=None, metavar="D0,D1,...",
+                    help="ONE process drives these HIP devices through rsv_multi_verify_batch_dev (one context and host thread "
+                         "per entry; a device may repeat), host-assembled bitmap, no collective.  Not combined with --gpus.")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU: K contexts, each verifying its own copy of the batch from its own host "
                          "thread (a step = K batches).  Small batches are latency-bound chains that leave the chip idle; "
@@ -274,6 +312,11 @@ def main():
         spec.loader.exec_module(launcher)
         sys.exit(launcher.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    if args.devices is not None:
+        if args.gpus != 1:
+            raise SystemExit("--devices is the one-process layout: not combined with --gpus")
+        return run_one_process(args)
+
     import rsvload
     rsv = rsvload.load_package(args.lib)
     from recursive_stwo_amd import sharding
@@ -297,12 +340,15 @@ def main():
 
     strong = args.total_proofs > 0
     n_total = args.total_proofs if strong else world * args.proofs
-    first, last = sharding.shard_range(n_total, rank, world)
-    n = last - first
     fixtures = WORKLOADS[args.workload]
-    d_blob, d_offsets, plen, tam, fix_idx = build_batch_on_device(torch, dev, n, first, fixtures)
+    # the partition: a job of fixed size is cut by rsv_shard_plan (contiguous, balanced by bytes: every rank computes the
+    # same cuts from the job's lengths); per-GPU batches of equal size (weak scaling) are rsv_shard_range's equal counts
+    plan = rsv.shard_plan(job_lengths(n_total, fixtures, args.order), world) if strong else None
+    first, last = (plan[0][rank], plan[1][rank]) if plan else sharding.shard_range(n_total, rank, world)
+    n = last - first
+    d_blob, d_offsets, plen, tam, fix_idx = build_batch_on_device(torch, dev, n, first, fixtures, args.order, n_total)
     total_bytes = int(plen.sum())
-    sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch)
+    sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch, plan=plan, exchange=args.exchange)
     if args.stage_times:  # the roofline's kernel time comes from HIP events on the verifier's streams
         try:
             sv.ctx.set_option("stage_times", "on")
@@ -412,7 +458,21 @@ def main():
             pass
         group = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver, "devices": devs}
 
+    # bytes of every rank's shard (what the partition balances)
+    shard_bytes = [total_bytes]
+    if dist.is_initialized():
+        sb = [None] * dist.get_world_size()
+        dist.all_gather_object(sb, total_bytes)
+        shard_bytes = sb
+    if args.exchange == "c":
+        v = rsv.lib.rsv_exchange_rccl_version()
+        exchange_backend = f"rsv_exchange (rccl {v // 10000}.{v // 100 % 100}.{v % 100})"
+    else:
+        exchange_backend = f"torch.distributed ({group['backend']})" if group["backend"] else "torch tensors, no process group (1 rank)"
+
     if rank != 0:
+        if args.exchange == "c":
+            sv.exchange.close()
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -660,14 +720,101 @@ def main():
                    "batches_in_flight": args.inflight, "knobs": args.knob,
                    "hint_outputs": sorted(k for k in (hints or {}) if k.startswith("d_")),
                    "flow_bytes_per_step_rank0": (int(hints["d_flow"].numel()) * 4 + int(hints["d_flow_swap"].numel())) if args.emit_flow else 0,
-                   "exchange": dict(group, collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
+                   "order": args.order,
+                   "partition": ("rsv_shard_plan: contiguous, balanced by bytes" if plan else "rsv_shard_range: contiguous, equal counts"),
+                   "shard_bytes": shard_bytes,
+                   "exchange": dict(group, backend=exchange_backend,
+                                    collectives="all_gather(accept bitmap) + all_reduce(count) per step, " + (
                        "gloo (rehearsal)" if rehearsal else ("nccl/RCCL" if world > 1 else "none (1 rank)")))},
         "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "valu": valu, "emulated_poseidon2": emulated,
         "recursion_circuit_witness": witness, "single_proof": single,
     }
     print(json.dumps(line), flush=True)
+    if args.exchange == "c":
+        sv.exchange.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def run_one_process(args):
+    """`--devices D0,D1,...`: the one-process layout of the C-ABI (rsv_multi_verify_batch_dev) — what the reference's own
+    driver is (one process walks the whole job).  One context and one host thread per entry, every shard resident on its
+    device, the job's bitmap and count assembled on the host: no collective.  Prints the standard line (its `roofline`
+    carries the whole-step figure only: the per-kernel clock belongs to the per-rank path)."""
+    import rsvload
+    rsv = rsvload.load_package(args.lib)
+    import torch
+    devices = [int(x) for x in args.devices.split(",") if x != ""]
+    world = len(devices)
+    if world < 1 or rsv.device_count() <= max(devices):
+        raise SystemExit("bench.py --devices needs every named HIP device: the product has no CPU fallback")
+    for kv in args.knob:
+        name, value = kv.split("=", 1)
+        rsv.set_default_option(name, value if value in rsv.OPTION_VALUES else int(value))
+    strong = args.total_proofs > 0
+    n_total = args.total_proofs if strong else world * args.proofs
+    fixtures = WORKLOADS[args.workload]
+    fcfg = fixture_configs(rsv, fixtures)
+    rows = [rsv._cfg_key(c) for c in fcfg]
+    table = sorted(set(rows))
+    if strong:
+        lo, hi = rsv.shard_plan(job_lengths(n_total, fixtures, args.order), world)
+    else:
+        lo, hi = zip(*[rsv.shard_range(n_total, r, world) for r in range(world)])
+    shards, shard_bytes, keep = [], [], []
+    for r, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        n = hi[r] - lo[r]
+        d_blob, d_offsets, plen, _, fix_idx = build_batch_on_device(torch, dev, n, lo[r], fixtures, args.order, n_total)
+        d_of = torch.from_numpy(np.array([table.index(rows[k]) for k in fix_idx], np.uint8)).to(dev) if len(table) > 1 else None
+        d_acc = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        shards.append({"d_blob": d_blob, "d_offsets": d_offsets, "n": n, "d_cfg_of": d_of, "d_accept": d_acc})
+        shard_bytes.append(int(plen.sum()))
+        keep.append((d_blob, d_offsets, d_of, d_acc))
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    mc = rsv.MultiContext(devices)
+    cfg_table = [rsv.PcsConfig(*k) for k in table]
+    for _ in range(args.warmup):
+        mc.verify_batch_dev(shards, cfg_table)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bitmap, count = mc.verify_batch_dev(shards, cfg_table)  # returns when every context is done and the bitmap assembled
+    dt = time.perf_counter() - t0
+    job_want = (np.arange(n_total) % 17 != 5).astype(np.uint8)
+    job = np.unpackbits(bitmap.view(np.uint8), bitorder="little")[:n_total]
+    if not np.array_equal(job, job_want) or count != int(job_want.sum()):
+        raise SystemExit("one-process path: the job's bitmap or count differs from the expected accept map")
+    for r, sh in enumerate(shards):
+        if not np.array_equal(sh["d_accept"][: sh["n"]].cpu().numpy(), job_want[lo[r]:hi[r]]):
+            raise SystemExit(f"one-process path: shard {r}'s accept bytes differ from the expected accept map")
+    ms_per_step = dt / args.steps * 1e3
+    algo_bytes = sum(shard_bytes) + n_total
+    gbps = algo_bytes / (ms_per_step * 1e-3) / 1e9
+    names = []
+    for d in devices:
+        pr = torch.cuda.get_device_properties(d)
+        names.append({"device_index": d, "name": pr.name, "uuid": str(getattr(pr, "uuid", ""))})
+    line = {
+        "metric": "recursive proofs verified/sec", "value": n_total * args.steps / dt, "unit": "proofs/s", "n_gpus": len(set(devices)),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32 (M31 modular integers)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_total} proofs per step over {world} context(s) of ONE process, {args.order} over {fixtures}, "
+                               "i%17==5 tampered (SURVEY §8d), full verify; the job's bitmap, count and every shard's accept bytes checked",
+                   "proofs_per_step": n_total, "parallelism": f"one process, contexts on devices {devices}", "knobs": args.knob, "order": args.order,
+                   "partition": "rsv_shard_plan: contiguous, balanced by bytes" if strong else "rsv_shard_range: contiguous, equal counts",
+                   "shard_bytes": shard_bytes,
+                   "exchange": {"backend": "rsv_multi (host assembly)", "world_size": world, "devices": names,
+                                "collectives": "none: one process owns every shard; bitmap slices come back over PCIe (n / 8 bytes)"}},
+        "roofline": {"bound": "valu", "nominal_bound": "hbm", "kernel": None, "achieved": gbps, "peak": HBM_PEAK_GBPS * len(set(devices)), "unit": "GB/s",
+                     "frac": gbps / (HBM_PEAK_GBPS * len(set(devices))), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "pipeline_ms": ms_per_step,
+                     "note": "whole-step figure (algorithmic bytes over the wall time of a blocking rsv_multi_verify_batch_dev call, "
+                             "against the named devices' HBM peak); the per-kernel roofline is the default path's"},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+    mc.close()
 
 
 if __name__ == "__main__":

@@ -208,9 +208,6 @@ typedef enum rsv_option {
     RSV_OPT_CAP_MID = 26,         /* with the cap's top in kernels of its own (RSV_OPT_CAP_TOP): 0 auto — a bucket of proofs whose dense cap levels
                                      fill the tree kernels' waves badly (80, 27, 11, 10 queries) hands its nodes over at the cap level, a
                                      lane per subtree walks the middle levels (k_cap_mid), k_cap_top the rest; 1 every bucket does, 2 none */
-    RSV_OPT_TREE_GUESTS = 27,     /* batches of several query counts, large enough for the paced Merkle kernels and the cap kernels: 0 / 1 the lanes
-                                     a workgroup's own proofs leave idle (three 80-query proofs fill 240 of 256) walk the paths of proofs
-                                     of another bucket of the launch (one 16-query proof), 2 they stay idle */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -92,17 +92,7 @@ inline void bucket_by_shape(const uint32_t* shape, uint32_t N, std::vector<Bucke
 // top-of-tree cap from level Lc down.  Lt: the level at which the tree kernels hand their nodes over to the cap kernels
 // (0: the whole cap inside the tree kernels); Lt2 <= Lt: the level from which k_cap_top (one lane per tree) walks to the
 // root; the levels between Lt and Lt2 belong to k_cap_mid (one lane per subtree).
-// Guests: the workgroups of an entry whose proofs leave lanes idle (three 80-query proofs fill 240 of 256) carry, in those
-// lanes, proofs of another entry of the same launch (one 16-query proof each).  The hosted proofs form an entry of their own
-// (own = 0: no workgroups of its own in the tree kernels; every other stage treats it like any entry); the host entry
-// names it: guest = its index in the group, gpb = hosted proofs per workgroup, gblocks = workgroups that carry some.
-struct Entry {
-    size_t bi; size_t c0; uint32_t cn, G, Lc, Lt, Lt2; size_t bytes;
-    uint32_t own = 0xFFFFFFFFu;  // slots that get workgroups of their own in the tree kernels (0xFFFFFFFF = all cn)
-    int guest = -1;
-    uint32_t gpb = 0, gblocks = 0;
-    uint32_t own_slots() const { return own == 0xFFFFFFFFu ? cn : own; }
-};
+struct Entry { size_t bi; size_t c0; uint32_t cn, G, Lc, Lt, Lt2; size_t bytes; };
 
 struct GroupPolicy {
     size_t budget;         // bytes of per-query workspace a group may use
@@ -111,7 +101,6 @@ struct GroupPolicy {
     bool flow;             // the pass writes PoseidonFlow records
     bool flow_cap_off;     // RSV_OPT_FLOW_CAP = 2
     bool cap_top;          // the last levels of the cap in k_cap_top
-    int guests = 0;        // RSV_OPT_TREE_GUESTS: 0 / 1 idle lanes of the tree kernels' workgroups carry proofs of another bucket, 2 never
     int cap_mid = 0;       // RSV_OPT_CAP_MID: 0 by the fill of the in-kernel cap levels, 1 hand over at the cap level wherever the cap kernels can take it, 2 never
 };
 
@@ -166,58 +155,6 @@ inline size_t entry_bytes(const Bucket& b, uint32_t G, size_t cn, uint32_t Lt, u
     return ((probe.off + 255) & ~(size_t)255) + 256;
 }
 
-// Guests of one group (see Entry).  A host is an entry that hands over at the cap level (its workgroups run no in-kernel
-// cap, so lanes of another geometry can sit beside its proofs) and leaves >= 4 lanes of a workgroup idle; its guests come
-// from the END of the entry that fills those lanes best, which is cut in two (or, if it is used up, becomes the hosted
-// entry itself).  Hosted proofs hand over at their own cap level.  `block`: lanes per workgroup of the tree kernels.
-inline void assign_guests(const std::vector<Bucket>& buckets, const GroupPolicy& pol, std::vector<Entry>& grp, uint32_t block = 256) {
-    if (pol.guests == 2 || pol.flow || !pol.cap_top || pol.tree_cap_off) return;
-    const size_t n0 = grp.size();
-    for (size_t h = 0; h < n0; h++) {
-        if (grp[h].own_slots() == 0 || grp[h].guest >= 0 || !grp[h].Lc || grp[h].Lt != grp[h].Lc) continue;
-        const uint32_t Gh = grp[h].G, pb = std::min<uint32_t>(block / Gh, 64u), spare = block - pb * Gh;
-        if (spare < 4 || pb >= 64) continue;
-        size_t best = n0;
-        uint32_t best_fill = 0;
-        for (size_t d = 0; d < n0; d++) {
-            const Entry& e = grp[d];
-            if (d == h || e.guest >= 0 || e.own_slots() != e.cn || !e.Lc || !e.Lt || e.G > spare) continue;  // not a host, not hosted, has a cap the cap kernels finish
-            bool is_host_candidate = e.Lt == e.Lc && block - std::min<uint32_t>(block / e.G, 64u) * e.G >= 4;
-            if (is_host_candidate) continue;
-            const uint32_t fill = std::min<uint32_t>(spare / e.G, 64u - pb) * e.G;
-            if (fill > best_fill || (fill == best_fill && best < n0 && e.G > grp[best].G)) { best = d; best_fill = fill; }
-        }
-        if (best == n0) continue;
-        const uint32_t Gd = grp[best].G, gpb = std::min<uint32_t>(spare / Gd, 64u - pb);
-        const uint32_t nblocks = (grp[h].own_slots() + pb - 1) / pb;
-        uint32_t take = (uint32_t)std::min<uint64_t>((uint64_t)nblocks * gpb, grp[best].cn);
-        take = take / gpb * gpb;
-        if (take == 0) continue;
-        uint32_t Lt, Lt2;
-        handover_levels(grp[best].Lc, Lt, Lt2);
-        size_t gi;
-        if (take == grp[best].cn) {  // the whole entry rides along
-            gi = best;
-        } else {
-            if (grp.size() >= pol.max_fused) break;
-            Entry g = grp[best];
-            g.c0 = grp[best].c0 + (grp[best].cn - take);
-            g.cn = take;
-            grp[best].cn -= take;
-            grp[best].bytes = entry_bytes(buckets[grp[best].bi], Gd, grp[best].cn, grp[best].Lt, grp[best].Lt2);
-            grp.push_back(g);
-            gi = grp.size() - 1;
-        }
-        grp[gi].own = 0;
-        grp[gi].Lt = Lt;
-        grp[gi].Lt2 = Lt2;
-        grp[gi].bytes = entry_bytes(buckets[grp[gi].bi], Gd, grp[gi].cn, Lt, Lt2);
-        grp[h].guest = (int)gi;
-        grp[h].gpb = gpb;
-        grp[h].gblocks = take / gpb;
-    }
-}
-
 // The batch is cut into GROUPS of at most max_fused entries whose workspaces fit the budget together; a group is ONE launch
 // per stage.  A uniform batch is one entry (several groups only when it exceeds the budget), a mixed batch normally one
 // group with an entry per n_queries.  Returns the workspace bytes the largest group needs.
@@ -226,20 +163,7 @@ inline size_t plan_groups(const std::vector<Bucket>& buckets, const GroupPolicy&
     size_t need = 0;
     std::vector<Entry> cur;
     size_t used = 0;
-    auto flush = [&]() {
-        if (cur.empty()) return;
-        {   // guests, if the group still fits its budget with them (hosted proofs hand over at their cap level: larger node arrays)
-            std::vector<Entry> with = cur;
-            assign_guests(buckets, pol, with);
-            size_t total = 0;
-            for (const Entry& e : with) total += e.bytes;
-            if (total <= std::max(pol.budget, used)) { cur.swap(with); used = total; }
-        }
-        groups.push_back(cur);
-        need = std::max(need, used);
-        cur.clear();
-        used = 0;
-    };
+    auto flush = [&]() { if (!cur.empty()) { groups.push_back(cur); need = std::max(need, used); cur.clear(); used = 0; } };
     // widest buckets first: their workgroups are the longest-running, and a launch's tail should be short ones
     for (size_t bk = buckets.size(); bk-- > 0;) {
         const size_t bi = bk;

@@ -107,10 +107,6 @@ struct MerkleArgs {
     unsigned long long *tcapm, *pcapm;
     uint32_t *tcapn2, *pcapn2;
     unsigned long long *tcapm2, *pcapm2;
-    // Guests (host_logic.hpp: Entry): n_own <= n slots get workgroups of their own in the tree kernels; the first gblocks
-    // workgroups of this set also carry, in the lanes its own proofs leave idle, gpb proofs each of argument set guest_set
-    // (workgroup bx: that set's slots bx * gpb ...), whose n_own is 0.
-    uint32_t n_own, guest_set, gpb, gblocks;
 };
 
 // ---------------------------------------------------------------- merkle_cap
@@ -246,14 +242,10 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 // permutation (poseidon2_row_half).  For launches of a few waves (a single proof: 64 paths per tree), where the walk is
 // a chain of dependent permutations and the row form's chain is a quarter as long: one proof's trace trees 285 -> 67 us, its call 1.15 -> 0.82 ms; 128 proofs 1.14 -> 0.91 ms; 512: slower (1.26 -> 1.54).
 // Stores and atomicOr's of the 16 threads coincide (same address, same value).
-// GUEST (a third instantiation, for launches of several buckets): the lanes a workgroup's own proofs leave idle walk the
-// paths of proofs of ANOTHER argument set (host_logic.hpp: Entry) — same code, the argument set chosen per lane.  Hosts and
-// guests hand their level-Lc nodes over to the cap kernels (no in-kernel cap: its lanes are dealt by one geometry).
-template <int BLOCK, bool FLOW = false, int PACE = 1, bool GUEST = false>
+template <int BLOCK, bool FLOW = false, int PACE = 1>
 __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE_WAVES)) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
-    static_assert(!GUEST || (!FLOW && PACE != FORM_ROW), "guests: plain lane form only");
     RSV_TAG(3);
-    RSV_FUSED_SELECT(f, a0, bx);
+    RSV_FUSED_SELECT(f, a, bx);
     constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
     const uint32_t tid = vlane<PACE>();
     row_rc_init<PACE>();
@@ -262,22 +254,16 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed;
     __shared__ uint32_t capfl[2][FLOW ? VB : 1];  // FLOW with a cap: see merkle_cap
-    const uint32_t per_block = VB / a0.pl.G;
-    const bool has_guests = GUEST && a0.gpb && bx < a0.gblocks;  // workgroup-uniform
-    const bool guest = has_guests && tid >= per_block * a0.pl.G;
-    const MerkleArgs& a = guest ? f.a[a0.guest_set] : a0;
-    const uint32_t G = a.pl.G, Lc = a.Lc;
-    const uint32_t gt = guest ? tid - per_block * a0.pl.G : tid;
-    const uint32_t gl = gt / G, j = gt % G;  // proof of this lane among its set's proofs in the workgroup, query
-    const uint32_t grp = guest ? per_block + gl : gl;  // ... among all proofs of the workgroup
-    const uint32_t slot_ = bx * (guest ? a0.gpb : per_block) + gl;
+    const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
+    const uint32_t grp = tid / G, j = tid % G;
+    const uint32_t slot_ = bx * per_block + grp;
     const int t = blockIdx.y;
-    const bool slot_ok = guest ? (gl < a0.gpb && slot_ < a.n) : (gl < per_block && slot_ < a.n_own);
+    const bool slot_ok = grp < per_block && slot_ < a.n;
     bool live = slot_ok;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq;
-    const uint32_t gbase = tid - j;  // first lane of this proof
+    const uint32_t gbase = grp * G;
     const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
     uint32_t M = 0, A = 0, B = 0, mx = 0, nc_leaf = 0, qv_n = 0, hw_n = 0, s_top = 0, nd_leaf = 0;
     const uint32_t *hw = nullptr, *rows = nullptr;
@@ -318,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
             }
         }
     }
-    const bool direct = a0.Lc && a0.Lt == a0.Lc;  // workgroup-uniform: level-Lc nodes go straight to the cap kernels (guests: always)
+    const bool direct = Lc && a.Lt == Lc;  // the level-Lc nodes go straight to the cap kernels (no in-kernel cap)
     if (!direct && Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
         d.active = live ? 1u : 0u;
@@ -343,10 +329,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
     __syncthreads();
     const uint32_t need = xneed;
     uint32_t buf = 0;  // toggles per exchange (not per level): a buffer is rewritten two barriers after its last read
-    const uint32_t lvl_hi = has_guests ? umax(a0.pl.maxM, f.a[a0.guest_set].pl.maxM) : a0.pl.maxM;
-    const uint32_t lvl_lo = has_guests ? umin(a0.Lc, f.a[a0.guest_set].Lc) : a0.Lc;
-    for (uint32_t lvl = lvl_hi; lvl > lvl_lo; lvl--) {  // child level
-        const bool on = live && lvl <= mx && lvl > Lc;
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
+        const bool on = live && lvl <= mx;
         const bool exch = (need >> lvl) & 1u;  // workgroup-uniform
         if (exch) {
             if (on) store_hash(xch[buf][tid], cur);
@@ -440,8 +424,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
             capfl[0][tid] = (live && fs.rec) ? fbase + flow_chunks(nc_leaf) + 1u + (mx - Lc) + extra : 0xFFFFFFFFu;
             capfl[1][tid] = live ? (qj >> (M - Lc)) : 0u;
         }
-        merkle_cap<VB, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a0.Lt, a0.tcapn,
-                                a0.tcapm, bx * per_block, a0.n_own, 4u, (uint32_t)t, capfl, G);
+        merkle_cap<VB, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, emit, mx - 1u, a.Lt, a.tcapn,
+                                a.tcapm, bx * per_block, a.n, 4u, (uint32_t)t, capfl, G);
     }
 }
 
@@ -455,11 +439,10 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
 // the lane itself from the sibling's children hash (another lane's, through xch2, or hashed from the witness pair,
 // which the circuit takes as a hint and does not hash).
 // PACE = FORM_ROW: on virtual lanes, as k_trace_merkle (one proof's FRI trees 435 -> 94 us).
-template <int BLOCK, bool FLOW = false, int PACE = 1, bool GUEST = false>
+template <int BLOCK, bool FLOW = false, int PACE = 1>
 __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_WAVES)) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
-    static_assert(!GUEST || (!FLOW && PACE != FORM_ROW), "guests: plain lane form only");
     RSV_TAG(4);
-    RSV_FUSED_SELECT(f, a0, bx);
+    RSV_FUSED_SELECT(f, a, bx);
     constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
     const uint32_t tid = vlane<PACE>();
     row_rc_init<PACE>();
@@ -473,22 +456,16 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
     __shared__ CapGroup capgrp[64];
     __shared__ uint32_t xneed[2];
     __shared__ uint32_t capfl[2][FLOW ? VB : 1];  // FLOW with a cap: see merkle_cap
-    const uint32_t per_block = VB / a0.pl.G;
-    const bool has_guests = GUEST && a0.gpb && bx < a0.gblocks;  // workgroup-uniform (see k_trace_merkle)
-    const bool guest = has_guests && tid >= per_block * a0.pl.G;
-    const MerkleArgs& a = guest ? f.a[a0.guest_set] : a0;
-    const uint32_t G = a.pl.G, Lc = a.Lc;
-    const uint32_t gt = guest ? tid - per_block * a0.pl.G : tid;
-    const uint32_t gl = gt / G, j = gt % G;
-    const uint32_t grp = guest ? per_block + gl : gl;
-    const uint32_t slot_ = bx * (guest ? a0.gpb : per_block) + gl;
+    const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
+    const uint32_t grp = tid / G, j = tid % G;
+    const uint32_t slot_ = bx * per_block + grp;
     const uint32_t slot = f.y_of[blockIdx.y];  // which FRI tree this grid row hashes (a permutation chosen by the host for small launches)
-    const bool slot_ok = guest ? (gl < a0.gpb && slot_ < a.n) : (gl < per_block && slot_ < a.n_own);
+    const bool slot_ok = grp < per_block && slot_ < a.n;
     bool live = slot_ok;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq && (slot == 0 || slot - 1 < m->n_inner);
-    const uint32_t gbase = tid - j;  // first lane of this proof
+    const uint32_t gbase = grp * G;
     const uint32_t* w = nullptr; const uint32_t* ent = nullptr; const PlanHdr* h = nullptr;
     const uint32_t* fl = nullptr; const uint32_t* leafv = nullptr; const ProofCtx* c = nullptr;
     const FriLayerRef* L = nullptr;
@@ -538,7 +515,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
             }
         }
     }
-    const bool direct = a0.Lc && a0.Lt == a0.Lc;  // workgroup-uniform: level-Lc nodes go straight to the cap kernels (guests: always)
+    const bool direct = Lc && a.Lt == Lc;  // the level-Lc nodes go straight to the cap kernels (no in-kernel cap)
     if (!direct && Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
         d.active = live ? 1u : 0u;
@@ -566,10 +543,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
     __syncthreads();
     const uint32_t needA = xneed[0], needB = xneed[1];
     uint32_t buf = 0;
-    const uint32_t lvl_hi = has_guests ? umax(a0.pl.maxM, f.a[a0.guest_set].pl.maxM) : a0.pl.maxM;
-    const uint32_t lvl_lo = has_guests ? umin(a0.Lc, f.a[a0.guest_set].Lc) : a0.Lc;
-    for (uint32_t lvl = lvl_hi; lvl > lvl_lo; lvl--) {  // child level
-        const bool on = live && lvl <= top && lvl > Lc;
+    for (uint32_t lvl = a.pl.maxM; lvl > Lc; lvl--) {  // child level
+        const bool on = live && lvl <= top;
         const uint32_t pl_ = lvl - 1;
         uint32_t fidx = 0;
         const bool exA = (needA >> lvl) & 1u, exB = (needB >> lvl) & 1u;  // workgroup-uniform
@@ -669,7 +644,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
             capfl[1][tid] = live ? (qj >> (M - Lc)) : 0u;
         }
         merkle_cap<VB, FLOW, PACE>(xch, capmask, capgrp, Lc, per_block, live, grp, live ? (qj >> (M - Lc)) : 0u, cur, live ? psib : nullptr, top - 2u,
-                                a0.Lt, a0.pcapn, a0.pcapm, bx * per_block, a0.n_own, 1u + a0.maxInner, slot, capfl, G);
+                                a.Lt, a.pcapn, a.pcapm, bx * per_block, a.n, 1u + a.maxInner, slot, capfl, G);
     }
 }
 

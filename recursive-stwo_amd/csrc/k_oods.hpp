@@ -63,32 +63,54 @@ __device__ __forceinline__ QM31 q_pow5(QM31 x) {
     QM31 x2 = q_mul(x, x);
     return q_mul(q_mul(x2, x2), x);
 }
+// The 16 QM31 words of the Poseidon AIR's round state, one lane's copy in LDS: word-major over the workgroup's 64 lanes
+// (st[(4 i + c) * 64 + lane]: conflict-free), so that the matrix steps can be out-of-line functions walking it with
+// run-time indices — as a register array behind a pointer it lived in scratch memory (1 440 B per lane, 1.5 GB of HBM
+// traffic per 65 536 proofs for a stage that reads 0.15 GB of samples).
+struct QState {
+    uint32_t* base;  // this lane's word 0
+    __device__ __forceinline__ QM31 get(int i) const {
+        return q_mk(base[(4 * i) * 64], base[(4 * i + 1) * 64], base[(4 * i + 2) * 64], base[(4 * i + 3) * 64]);
+    }
+    __device__ __forceinline__ void set(int i, QM31 v) const {
+        base[(4 * i) * 64] = v.a.a; base[(4 * i + 1) * 64] = v.a.b; base[(4 * i + 2) * 64] = v.b.a; base[(4 * i + 3) * 64] = v.b.b;
+    }
+};
+constexpr int QSTATE_WORDS = 16 * 4 * 64;  // per workgroup of 64 lanes
 // poseidon.rs:12-71 over QM31
-__device__ inline void q_m4(QM31* x) {
-    QM31 t0 = q_add(x[0], x[1]), t02 = q_dbl(t0), t1 = q_add(x[2], x[3]), t12 = q_dbl(t1);
-    QM31 t2 = q_add(q_dbl(x[1]), t1), t3 = q_add(q_dbl(x[3]), t0);
+__device__ inline void q_m4(QState s, int g) {
+    const QM31 x0 = s.get(g), x1 = s.get(g + 1), x2 = s.get(g + 2), x3 = s.get(g + 3);
+    QM31 t0 = q_add(x0, x1), t02 = q_dbl(t0), t1 = q_add(x2, x3), t12 = q_dbl(t1);
+    QM31 t2 = q_add(q_dbl(x1), t1), t3 = q_add(q_dbl(x3), t0);
     QM31 t4 = q_add(q_dbl(t12), t3), t5 = q_add(q_dbl(t02), t2);
-    x[0] = q_add(t3, t5); x[1] = t5; x[2] = q_add(t2, t4); x[3] = t4;
+    s.set(g, q_add(t3, t5)); s.set(g + 1, t5); s.set(g + 2, q_add(t2, t4)); s.set(g + 3, t4);
 }
-__device__ __noinline__ void q_external(QM31* s) {
-    for (int g = 0; g < 4; g++) q_m4(s + 4 * g);
+__device__ __noinline__ void q_external(QState s) {
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) q_m4(s, 4 * g);
+#pragma unroll 1
     for (int j = 0; j < 4; j++) {
-        QM31 sum = q_add(q_add(s[j], s[j + 4]), q_add(s[j + 8], s[j + 12]));
-        for (int g = 0; g < 4; g++) s[4 * g + j] = q_add(s[4 * g + j], sum);
+        const QM31 a = s.get(j), b = s.get(j + 4), c = s.get(j + 8), d = s.get(j + 12);
+        const QM31 sum = q_add(q_add(a, b), q_add(c, d));
+        s.set(j, q_add(a, sum)); s.set(j + 4, q_add(b, sum)); s.set(j + 8, q_add(c, sum)); s.set(j + 12, q_add(d, sum));
     }
 }
-__device__ __noinline__ void q_internal(QM31* s) {
-    QM31 sum = s[0];
-    for (int i = 1; i < 16; i++) sum = q_add(sum, s[i]);
-    s[0] = q_add(s[0], q_add(q_dbl(s[0]), sum));
-    for (int i = 1; i < 16; i++) s[i] = q_add(q_mul_m(s[i], 1u << (i + 1)), sum);
+__device__ __noinline__ void q_internal(QState s) {
+    const QM31 s0 = s.get(0);
+    QM31 sum = s0;
+#pragma unroll 1
+    for (int i = 1; i < 16; i++) sum = q_add(sum, s.get(i));
+    s.set(0, q_add(s0, q_add(q_dbl(s0), sum)));
+#pragma unroll 1
+    for (int i = 1; i < 16; i++) s.set(i, q_add(q_mul_m(s.get(i), 1u << (i + 1)), sum));
 }
 
 // The 86-constraint accumulator and the value it must equal (composition/src/lib.rs:60-120) for one proof whose
 // sampled values sit at their fixed word offsets behind `w`.  Shared by k_oods and by the probe k_oods_probe
 // (rsv_oods_eval), so that the evaluation can be checked on its own, on arbitrary samples.
+// st: this lane's QState (LDS of the calling kernel: QSTATE_WORDS words per 64 lanes).
 __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum, QM31 z,
-                                 QM31 alpha, QM31 rc, QM31 ox, QM31& acc_out, QM31& expected_out) {
+                                 QM31 alpha, QM31 rc, QM31 ox, QState st, QM31& acc_out, QM31& expected_out) {
     EvalCtx e;
     e.rc = rc; e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
     const QM31 one = q_one();
@@ -120,34 +142,40 @@ __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32
         QM31 is_first = e.smp(pre), is_last = e.smp(pre + 1), is_full = e.smp(pre + 2), round_id = e.smp(pre + 3);
         QM31 not_first = q_sub(one, is_first), not_last = q_sub(one, is_last), is_partial = q_sub(not_first, is_full);
         QM31 swap_val = e.smp(mid), one_minus_swap = q_sub(one, swap_val);
-        QM31 st[16];
+#pragma unroll 1
         for (int i = 0; i < 16; i++) {
             QM31 lo = e.smp(in + (i & 7)), hi = e.smp(in + (i & 7) + 8);
-            st[i] = i < 8 ? q_add(q_mul(lo, one_minus_swap), q_mul(hi, swap_val))
-                          : q_add(q_mul(lo, swap_val), q_mul(hi, one_minus_swap));
+            st.set(i, i < 8 ? q_add(q_mul(lo, one_minus_swap), q_mul(hi, swap_val))
+                            : q_add(q_mul(lo, swap_val), q_mul(hi, one_minus_swap)));
         }
         q_external(st);
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_first, q_sub(st[i], e.smp(out + i))));
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_first, q_sub(st.get(i), e.smp(out + i))));
+#pragma unroll 1
         for (int i = 0; i < 16; i++) {
             QM31 full = q_pow5(q_add(e.smp(in + i), e.smp(rc0 + i)));
             QM31 mi = e.smp(mid + i);
             e.constraint(q_mul(is_full, q_sub(mi, full)));
-            st[i] = mi;
+            st.set(i, mi);
         }
         q_external(st);
-        for (int i = 0; i < 16; i++) st[i] = q_pow5(q_add(st[i], e.smp(rc1 + i)));
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) st.set(i, q_pow5(q_add(st.get(i), e.smp(rc1 + i))));
         q_external(st);
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_full, q_sub(e.smp(out + i), st[i])));
-        for (int i = 0; i < 16; i++) st[i] = e.smp(in + i);
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_full, q_sub(e.smp(out + i), st.get(i))));
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) st.set(i, e.smp(in + i));
 #pragma unroll 1
         for (int r = 0; r < 14; r++) {
-            QM31 v = q_pow5(q_add(st[0], e.smp(rc0 + r)));
+            QM31 v = q_pow5(q_add(st.get(0), e.smp(rc0 + r)));
             QM31 mi = e.smp(mid + r);
             e.constraint(q_mul(is_partial, q_sub(mi, v)));
-            st[0] = mi;
+            st.set(0, mi);
             q_internal(st);
         }
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_partial, q_sub(e.smp(out + i), st[i])));
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_partial, q_sub(e.smp(out + i), st.get(i))));
         QM31 ext1 = e.smp(pre + 36), ext2 = e.smp(pre + 37), ext1_nz = e.smp(pre + 38), ext2_nz = e.smp(pre + 39);
         QM31 in_left = q_dbl(round_id), in_right = q_add(in_left, one), out_left = q_add(in_right, one),
              out_right = q_add(out_left, one);
@@ -353,7 +381,8 @@ __global__ __launch_bounds__(64, 4) void k_oods(const uint8_t* __restrict__ blob
         if (!q_eq(q_add(q_add(sum, poseidon_sum), plonk_sum), q_zero())) flags |= 1u << R_LOGUP;
     }
     QM31 acc, expected;
-    oods_eval(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), acc, expected);
+    __shared__ uint32_t qstate[QSTATE_WORDS];
+    oods_eval(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), QState{qstate + threadIdx.x}, acc, expected);
     if (!q_eq(acc, expected)) flags |= 1u << R_COMPOSITION;
     if (flags) atomicOr(&c.flags, flags);
 }
@@ -411,8 +440,9 @@ __global__ __launch_bounds__(64, 4) void k_oods_probe(const uint32_t* __restrict
     if (i >= n) return;
     const uint32_t* pr = params + (size_t)i * OODS_PARAM_WORDS;
     QM31 acc, expected;
+    __shared__ uint32_t qstate[QSTATE_WORDS];
     oods_eval(prefix + (size_t)i * prefix_words, pr[0], pr[1], ldq(pr + 2), ldq(pr + 6), ldq(pr + 10), ldq(pr + 14), ldq(pr + 18),
-              ldq(pr + 22), acc, expected);
+              ldq(pr + 22), QState{qstate + threadIdx.x}, acc, expected);
     stq(out + (size_t)i * 8, acc);
     stq(out + (size_t)i * 8 + 4, expected);
 }

@@ -408,10 +408,9 @@ __device__ __forceinline__ Hash8 zero8() {
     for (int i = 0; i < 8; i++) h.w[i] = 0;
     return h;
 }
-#ifndef RSV_HALF_INSTANCES
-#define RSV_HALF_INSTANCES 2   // 1: one out-of-line instance with a run-time half selector (51 VGPRs: the Merkle kernels spill 32 B per lane around the calls); 2: one instance per half (39 VGPRs each, no spill).  Same step time (35.06-35.14 vs 35.10-35.16 ms); 2 moves 1 GB less
-#endif
-#if RSV_HALF_INSTANCES == 2
+// (Until round 4 a second form stood beside this one — a single out-of-line instance with a run-time half selector, 51
+// VGPRs, the Merkle kernels spilling 32 B per lane around its calls; same step time, 1 GB more traffic.  Its callers moved
+// to the template arguments below, so it no longer compiled: removed.)
 // One out-of-line instance per output half and pacing.  The Merkle kernels (several waves per SIMD wherever a launch
 // fills the machine) call the PACED ones; the lane-form transcript — one wave per SIMD for 65 536 proofs — the unpaced
 // ones (k_transcript: 3.21 -> 2.66 ms).  A choice per call site by launch size (tried: small batches' trees unpaced, one
@@ -480,24 +479,6 @@ __device__ __forceinline__ State16 poseidon2_full(State16 st) {
 // the lane of a kernel's own indexing: a thread (lane forms) or a DPP row of 16 threads that all compute the same (row form)
 template <int PACE>
 __device__ __forceinline__ uint32_t vlane() { return PACE == FORM_ROW ? threadIdx.x >> 4 : threadIdx.x; }
-#else
-// Out-of-line instance shared by every hash of the verify kernels: one half of the output (hi = 0 rate, 1 capacity).
-__device__ __noinline__ Hash8 poseidon2_half(State16 st, uint32_t hi) {
-#ifdef RSV_COUNT_PERMS
-    {
-        const unsigned long long m = __ballot(1);
-        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) {
-            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u)], (unsigned long long)__builtin_popcountll(m));
-            atomicAdd(&g_perm_counter[2 * (s_perm_tag & 7u) + 1], 1ull);
-        }
-    }
-#endif
-    Hash8 h;
-    // hi is a constant of the call site, the same on every active lane: held in an SGPR, not in a 41st VGPR
-    PermT<true>::poseidon2_inline_half(st.s, (uint32_t)__builtin_amdgcn_readfirstlane((int)hi), h.w);
-    return h;
-}
-#endif
 template <int PACE = 1>
 __device__ __forceinline__ Hash8 perm_rate(const Hash8& l, const Hash8& r) { return poseidon2_half<PACE>(join(l, r), 0u); }
 template <int PACE = 1>

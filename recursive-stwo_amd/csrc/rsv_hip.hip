@@ -52,7 +52,6 @@ struct Options {
     int tree_pace = 0;         // 0 auto (by batch size), 1 the tree kernels on the paced permutation instances, 2 on the unpaced ones, 3 in the row form (16 threads per path)
     int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
     int cap_mid = 0;           // 0 auto (buckets whose in-kernel cap levels fill their waves badly), 1 every bucket hands over at the cap level (k_cap_mid + k_cap_top), 2 none
-    int tree_guests = 0;       // 0 / 1 idle lanes of the tree kernels' workgroups carry proofs of another bucket of the launch, 2 never
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
     int witness_small_log = 0;        // 0 default, else 1 + log2(proofs per workgroup) of that form
@@ -260,7 +259,6 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_STAGE_TIMES: return tri(&o.stage_times);
         case RSV_OPT_QUERY_FORM: return tri(&o.query_form);
         case RSV_OPT_CAP_MID: return tri(&o.cap_mid);
-        case RSV_OPT_TREE_GUESTS: return tri(&o.tree_guests);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;
             o.witness_walk_log = (int)value; return RSV_OK;

@@ -34,6 +34,31 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, hi
 
 
+def shard_plan(lens, world: int):
+    """Work-balanced contiguous cuts (rsv_shard_plan, restated): rank r owns [lo[r], hi[r]); the cut between ranks r - 1 and r
+    is the proof boundary nearest to r / world of the job's bytes — bytes are the work (the verifier is permutation-bound
+    and every shape of the reference costs 21-26.5 proof bytes per permutation).  For a job that arrives ordered by level
+    (examples/multi-proofs/src/main.rs:198-295) equal-count shards differ 4.5 x in bytes.  tests/test_sharding.py holds this
+    restatement against the C entry point."""
+    ln = [int(x) for x in lens]
+    n, total = len(ln), sum(ln)
+    lo, hi, at, pre = [], [], 0, 0
+    for r in range(world):
+        lo.append(at)
+        if r + 1 == world:
+            hi.append(n)
+            break
+        target = total * (r + 1) // world
+        while at < n and pre + ln[at] <= target:
+            pre += ln[at]
+            at += 1
+        if at < n and pre < target and (target - pre) * 2 > ln[at]:
+            pre += ln[at]
+            at += 1
+        hi.append(at)
+    return lo, hi
+
+
 def bitmap_words(n: int) -> int:
     return (n + 31) // 32
 
@@ -58,10 +83,18 @@ class BitmapExchange:
     Buffers are allocated once: `local` (this rank's slice — the verifier writes its bitmap straight into it),
     `gathered` (world x slice_words), `count` (1 x int64: local accepts in, job total out)."""
 
-    def __init__(self, n_total: int, rank: int, world: int, dist, torch, device):
+    def __init__(self, n_total: int, rank: int, world: int, dist, torch, device, plan=None):
+        """plan = (lo, hi) of every rank (shard_plan's cuts, or the caller's): slices of unequal width, every rank sends the
+        widest's words; None: the job is cut by shard_range."""
         self.n_total, self.rank, self.world, self.dist, self.torch = n_total, rank, world, dist, torch
-        self.lo, self.hi = shard_range(n_total, rank, world)
-        self.slice_words = max(1, bitmap_words(shard_range(n_total, 0, world)[1]))  # rank 0 owns a largest shard
+        if plan is None:
+            plan = tuple(zip(*[shard_range(n_total, r, world) for r in range(world)]))
+        self.plan = ([int(x) for x in plan[0]], [int(x) for x in plan[1]])
+        if len(self.plan[0]) != world or self.plan[0][0] != 0 or self.plan[1][-1] != n_total or \
+                any(self.plan[0][r + 1] != self.plan[1][r] for r in range(world - 1)) or any(h < l for l, h in zip(*self.plan)):
+            raise ValueError("a shard plan is contiguous from 0 to n_total, one [lo, hi) per rank")
+        self.lo, self.hi = self.plan[0][rank], self.plan[1][rank]
+        self.slice_words = max(1, max(bitmap_words(h - l) for l, h in zip(*self.plan)))  # the widest shard's
         self.device = device
         self.local = torch.zeros(self.slice_words, dtype=torch.int32, device=device)
         self.gathered = torch.zeros(world * self.slice_words, dtype=torch.int32, device=device)
@@ -99,7 +132,7 @@ class BitmapExchange:
         g = self.gathered.cpu().numpy().view(np.uint32).reshape(self.world, self.slice_words)
         out = np.zeros(self.n_total, np.uint8)
         for r in range(self.world):
-            lo, hi = shard_range(self.n_total, r, self.world)
+            lo, hi = self.plan[0][r], self.plan[1][r]
             out[lo:hi] = unpack_bitmap(g[r], hi - lo)
         return out
 
@@ -107,13 +140,49 @@ class BitmapExchange:
         return int(self.count.item())
 
 
-def gather_accept_bitmap(local_bitmap, n_total: int, rank: int, world: int, dist, torch):
+def gather_accept_bitmap(local_bitmap, n_total: int, rank: int, world: int, dist, torch, plan=None):
     """Functional form of BitmapExchange for a caller that already holds its shard's bitmap as an int32 tensor:
     returns the job's accept vector (uint8[n_total]) on every rank."""
-    ex = BitmapExchange(n_total, rank, world, dist, torch, local_bitmap.device)
+    ex = BitmapExchange(n_total, rank, world, dist, torch, local_bitmap.device, plan=plan)
     ex.local[: local_bitmap.numel()] = local_bitmap
     ex.run()
     return ex.assemble()
+
+
+class CExchange:
+    """The same step through the C-ABI (rsv_exchange_*: ONE ncclAllGather + ONE ncclAllReduce issued by the library on the
+    verifier's own stream, RCCL bound by dlopen) — what a Rust host would call; same buffers and `assemble()` as
+    BitmapExchange.  The RCCL unique id travels through the torch process group (a host-side broadcast: any channel would
+    do); torch.distributed carries nothing of the data path."""
+
+    def __init__(self, rsv, ctx, n_total: int, rank: int, world: int, dist, torch, device, plan=None):
+        self.n_total, self.rank, self.world, self.torch = n_total, rank, world, torch
+        uid = [rsv.exchange_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        self.x = rsv.Exchange(ctx, uid[0], rank, world, n_total, plan=plan)
+        if plan is None:
+            plan = tuple(zip(*[shard_range(n_total, r, world) for r in range(world)]))
+        self.plan = ([int(v) for v in plan[0]], [int(v) for v in plan[1]])
+        self.lo, self.hi, self.slice_words = self.x.lo, self.x.hi, self.x.slice_words
+        assert (self.lo, self.hi) == (self.plan[0][rank], self.plan[1][rank])
+        self.local = torch.zeros(self.slice_words, dtype=torch.int32, device=device)
+        self.gathered = torch.zeros(world * self.slice_words, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        self._rsv = rsv
+
+    def run(self):
+        self.x.run(self.local, self.gathered, self.count)  # enqueued on the context's stream, behind the verifying pass
+
+    def assemble(self) -> np.ndarray:
+        g = self.gathered.cpu().numpy().view(np.uint32).reshape(self.world, self.slice_words)
+        return self._rsv.exchange_assemble(self.n_total, self.world, g, plan=self.plan)[0]
+
+    def total_accepted(self) -> int:
+        return int(self.count.item())
+
+    def close(self):
+        self.x.close()
 
 
 class ShardedVerifier:
@@ -125,13 +194,20 @@ class ShardedVerifier:
 
     step() = rsv_verify_hints_dev on the shard (verdicts + the accept bitmap and count into the exchange slice) ->
     all-gather + all-reduce.  Nothing blocks the host: the verifier's stream is ordered before torch's current stream (on which
-    the collectives are enqueued) with an event."""
+    the collectives are enqueued) with an event.
+    plan: (lo, hi) of every rank — shard_plan's byte-balanced cuts for a job of mixed shapes; None: shard_range.
+    exchange: "torch" (torch.distributed collectives; what the multi-rank tests rehearse) or "c" (rsv_exchange_* through the
+    C-ABI, the library's own RCCL calls on the verifier's stream)."""
 
-    def __init__(self, rsv, n_total: int, rank: int, world: int, device_index: int, dist, torch):
+    def __init__(self, rsv, n_total: int, rank: int, world: int, device_index: int, dist, torch, plan=None, exchange: str = "torch"):
         self.rsv, self.torch = rsv, torch
         dev = torch.device("cuda", device_index)
         self.ctx = rsv.Context(device_index)
-        self.exchange = BitmapExchange(n_total, rank, world, dist, torch, dev)
+        self.c_exchange = exchange == "c"
+        if self.c_exchange:
+            self.exchange = CExchange(rsv, self.ctx, n_total, rank, world, dist, torch, dev, plan=plan)
+        else:
+            self.exchange = BitmapExchange(n_total, rank, world, dist, torch, dev, plan=plan)
         self.n_local = self.exchange.hi - self.exchange.lo
         self.d_accept = torch.zeros(max(self.n_local, 1), dtype=torch.uint8, device=dev)
         self.d_reason = torch.zeros(max(self.n_local, 1), dtype=torch.uint8, device=dev)
@@ -142,7 +218,8 @@ class ShardedVerifier:
         # (rsv_hints_out::d_accept_bitmap: the kernel that writes the verdicts packs them)
         self.ctx.verify_hints(d_blob, d_offsets, self.n_local, self.d_accept, self.d_reason, cfg=cfg, **kw, **(hints or {}),
                               d_accept_bitmap=self.exchange.local, d_accept_count=self.exchange.count)
-        self.ctx.release_to_torch()
+        if not self.c_exchange:
+            self.ctx.release_to_torch()
         self.exchange.run()
 
     def synchronize(self):
@@ -150,6 +227,8 @@ class ShardedVerifier:
         self.torch.cuda.synchronize()
 
     def close(self):
+        if self.c_exchange:
+            self.exchange.close()
         self.ctx.close()
 
 

@@ -185,36 +185,21 @@ static void check_buckets(const std::vector<uint32_t>& shape, uint32_t N, size_t
     CHECK(at == live);
     // groups: every slot of every bucket in exactly one entry; a group within the budget unless it is a single minimum entry
     std::vector<std::vector<host::Entry>> groups;
-    const host::GroupPolicy pol{budget, max_fused, false, false, false, cap_top, (int)((N + 2 * budget) % 3), (int)((N + budget) % 3)};  // RSV_OPT_TREE_GUESTS, RSV_OPT_CAP_MID: every setting over the runs
+    const host::GroupPolicy pol{budget, max_fused, false, false, false, cap_top, (int)((N + budget) % 3)};  // RSV_OPT_CAP_MID: every setting over the runs
     const size_t need = host::plan_groups(buckets, pol, groups);
     std::vector<std::vector<std::pair<size_t, size_t>>> ranges(buckets.size());
     size_t worst = 0;
     for (const auto& g : groups) {
         CHECK(!g.empty() && g.size() <= max_fused);
-        size_t used = 0, plain = 0;
-        std::vector<int> hosted_by(g.size(), -1);
-        for (size_t k = 0; k < g.size(); k++) {
-            const host::Entry& e = g[k];
+        size_t used = 0;
+        for (const host::Entry& e : g) {
             CHECK(e.bi < buckets.size() && e.cn > 0 && e.c0 + e.cn <= buckets[e.bi].count);
             CHECK(e.G >= 4 && e.G >= buckets[e.bi].G && e.Lc <= 6 && e.Lt <= e.Lc && e.Lt2 <= 3 && e.Lt2 <= e.Lt && e.Lt - e.Lt2 <= 3 && (e.Lt - e.Lt2 != 1) && (e.Lt == 0 || (e.Lc >= 3 && e.Lt2 >= 2)));
             CHECK(e.bytes == host::entry_bytes(buckets[e.bi], e.G, e.cn, e.Lt, e.Lt2));
-            CHECK(e.own_slots() == e.cn || e.own_slots() == 0);
             ranges[e.bi].push_back({e.c0, e.cn});
             used += e.bytes;
-            uint32_t Lc0, Lt0, Lt20;
-            host::cap_levels(buckets[e.bi], pol, 256u, Lc0, Lt0, Lt20);
-            plain += host::entry_bytes(buckets[e.bi], e.G, e.cn, Lt0, Lt20);
-            if (e.guest >= 0) {  // a host: hands over at its cap level, the guests fit its idle lanes and its group table
-                CHECK(pol.guests != 2 && cap_top && (size_t)e.guest < g.size() && (size_t)e.guest != k && hosted_by[e.guest] == -1);
-                hosted_by[e.guest] = (int)k;
-                const host::Entry& q = g[e.guest];
-                const uint32_t pb = 256u / e.G;
-                CHECK(e.own_slots() == e.cn && e.Lc && e.Lt == e.Lc && q.own_slots() == 0 && q.guest < 0 && q.Lc && q.Lt == q.Lc);
-                CHECK(e.gpb >= 1 && pb + e.gpb <= 64 && pb * e.G + e.gpb * q.G <= 256 && e.gblocks * e.gpb == q.cn && e.gblocks <= (e.cn + pb - 1) / pb);
-            } else CHECK(e.gpb == 0 && e.gblocks == 0);
         }
-        for (size_t k = 0; k < g.size(); k++) CHECK((g[k].own_slots() == 0) == (hosted_by[k] >= 0));  // hosted <=> some entry of the group names it
-        CHECK(used <= budget || used <= plain || g.size() == 1 || g.back().cn <= 1024);
+        CHECK(used <= budget || g.size() == 1 || g.back().cn <= 1024);
         worst = std::max(worst, used);
     }
     for (size_t bi = 0; bi < buckets.size(); bi++) {  // every slot of every bucket in exactly one entry

@@ -17,7 +17,18 @@ static struct sigaction g_prev[NSIG];
 static int g_fd = 2;
 static const int g_signals[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL};
 
+static volatile sig_atomic_t g_inside = 0;
+
 static void on_fatal(int sig, siginfo_t* info, void* uc) {
+    /* A fault INSIDE this handler — unwinding a smashed stack, which is the very case it exists for — must not come back
+     * here: the second entry restores the default action and re-raises, so the process dies with its signal instead of
+     * spinning or running the alternate stack over.  (The signal is also blocked while the handler runs: no SA_NODEFER.) */
+    if (g_inside) {
+        signal(sig, SIG_DFL);
+        raise(sig);
+        return;
+    }
+    g_inside = 1;
     static const char head[] = "\n=== native backtrace (tests/native_backtrace.c) ===\n";
     static const char tail[] = "=== end of native backtrace ===\n";
     void* frames[64];
@@ -44,7 +55,7 @@ int rsv_test_install_native_backtrace(int fd) {
         struct sigaction sa;
         memset(&sa, 0, sizeof sa);
         sa.sa_sigaction = on_fatal;
-        sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
         sigemptyset(&sa.sa_mask);
         if (sigaction(g_signals[k], &sa, &g_prev[g_signals[k]]) != 0) return -1;
     }

@@ -47,9 +47,7 @@ def mixed():
              "chain": ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
                        "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]}
     rsv.set_default_option("tree_cap", "on")
-    for label, names, guests in [(k, v, g) for k, v in mixes.items() for g in (("auto",) if k == "standard" else ("off", "auto"))]:
-        rsv.set_default_option("tree_guests", guests)
-        label = f"{label} (guests {guests})"
+    for label, names in mixes.items():
         proofs = [open(os.path.join(ROOT, "tests", "golden", "proofs", f), "rb").read() for f in names]
         want = sum(ob.perm_count(p) for p in proofs) / len(proofs)
         n = 4160 if label.startswith("chain") else 4096

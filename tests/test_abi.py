@@ -72,7 +72,7 @@ def test_options_are_explicit_and_validated(rsv):
     assert lib.rsv_ctx_set_option(None, 999, 1) == -2          # RSV_E_SIZE: unknown option
     assert lib.rsv_ctx_set_option(None, 0, 1) == -2
     for name in ("transcript_form", "transcript_split", "oods_form", "qconst_form", "plan_form", "tree_cap", "overlap_trees",
-                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "stage_times", "query_form"):
+                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "stage_times", "query_form", "cap_mid"):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], 3) == -5, name   # RSV_E_RANGE
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], -1) == -5, name
         for v in (2, 1, 0):
@@ -91,6 +91,76 @@ def test_options_are_explicit_and_validated(rsv):
                 assert "getenv" not in open(os.path.join(root, f)).read(), f
     syms = subprocess.run(["nm", "-D", "--undefined-only", rsv.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in syms
+
+
+def test_shape_limits_are_api_not_parse_errors(rsv):
+    """include/rsv.h names the library's shape limits (RSV_MAX_*): a CONFIGURATION beyond them is RSV_E_SIZE from every entry
+    point that takes an rsv_cfg_set — before any device work, so it shows without a GPU — never n proofs rejected as
+    RSV_R_PARSE.  rsv_cfg_check tells in advance."""
+    ok = rsv.PcsConfig(20, 5, 8, 16)
+    assert rsv.cfg_check(ok) and rsv.cfg_check(rsv.PcsConfig(30, 16, 16, 128)) and rsv.cfg_check(rsv.PcsConfig(0, 1, 0, 1))
+    assert rsv.lib.rsv_cfg_check(None) == -1
+    beyond = [rsv.PcsConfig(20, 5, 8, 129), rsv.PcsConfig(20, 5, 8, 0), rsv.PcsConfig(20, 17, 8, 16), rsv.PcsConfig(20, 0, 8, 16),
+              rsv.PcsConfig(20, 5, 17, 16), rsv.PcsConfig(31, 5, 8, 16)]
+    proof = b"\0" * 64
+    for cfg in beyond:
+        assert not rsv.cfg_check(cfg)
+        for call in (lambda: rsv.verify_batch([proof], cfg),                       # rsv_verify_batch
+                     lambda: rsv.verify_batch([proof, proof], [ok, cfg]),          # one bad configuration in a set of two
+                     lambda: rsv.verify_batch([], cfg)):                           # even for an empty batch
+            with pytest.raises(rsv.RsvError) as e:
+                call()
+            assert e.value.code == -2, (rsv._cfg_key(cfg), e.value.code)          # RSV_E_SIZE, not RSV_E_DEVICE (-3)
+    # the limits in the header are the ones the kernels are compiled with
+    hdr = open(os.path.join(ROOT, "include", "rsv.h")).read()
+    lay = open(os.path.join(ROOT, "recursive-stwo_amd", "csrc", "layout.hpp")).read()
+    import re
+    for macro, const in (("RSV_MAX_QUERIES", "MAXQ"), ("RSV_MAX_LOG_SIZE", "MAX_LOG"), ("RSV_MAX_FRI_INNER", "MAX_INNER")):
+        assert re.search(rf"#define {macro} (\d+)", hdr).group(1) == re.search(rf"constexpr int {const} = (\d+);", lay).group(1)
+
+
+def test_shard_plan_balances_the_level_ordered_chain(rsv):
+    """rsv_shard_plan: contiguous cuts balanced by bytes.  The reference's own job arrives ordered by level
+    (examples/multi-proofs/src/main.rs:198-295: level1-5 ... level13-1, 435 KB down to 76 KB): 13 x 4 096 proofs in level
+    order over 8 ranks — cut by count rank 0 carries 4.5 x the bytes of rank 7, cut by the plan every rank the same within
+    1.1 (missing 3).  No device needed."""
+    from tests.conftest import read_proof
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+             "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]
+    lens = np.repeat(np.array([len(read_proof(nm)) for nm in names], dtype=np.uint64), 4096)
+    n, world = len(lens), 8
+    pre = np.concatenate([[0], np.cumsum(lens)])
+    by_count = [rsv.shard_range(n, r, world) for r in range(world)]
+    b = [int(pre[hi] - pre[lo]) for lo, hi in by_count]
+    assert max(b) / min(b) > 4.0                                                   # what the plan is for
+    lo, hi = rsv.shard_plan(lens, world)
+    assert lo[0] == 0 and hi[-1] == n and all(lo[r + 1] == hi[r] for r in range(world - 1))
+    b = [int(pre[h] - pre[l]) for l, h in zip(lo, hi)]
+    assert max(b) / min(b) <= 1.1 and max(b) - min(b) <= 2 * int(lens.max())
+    # a uniform job: the plan is rsv_shard_range up to one proof per cut
+    lo, hi = rsv.shard_plan(np.full(1000, 108896, np.uint64), 7)
+    assert all(abs(lo[r] - rsv.shard_range(1000, r, 7)[0]) <= 1 for r in range(7))
+    # degenerate jobs: more ranks than proofs (empty shards), an empty job, one giant proof, zero-length proofs
+    for ln, w in (([5, 5, 5], 8), ([], 4), ([1, 1, 10 ** 9, 1], 3), ([0, 0, 0, 0], 2)):
+        lo, hi = rsv.shard_plan(np.array(ln, np.uint64), w)
+        assert lo[0] == 0 and hi[-1] == len(ln) and all(lo[r + 1] == hi[r] and hi[r] >= lo[r] for r in range(w - 1))
+    assert rsv.lib.rsv_shard_plan(None, 0, 0, None, None) == -1
+    lo_a, hi_a = (ctypes.c_size_t * 2)(), (ctypes.c_size_t * 2)()
+    assert rsv.lib.rsv_shard_plan(None, 0, 5000, lo_a, hi_a) == -2                 # world beyond 4 096
+    # the planned exchange's host half: slices of unequal width, garbage above a shard's own bits is masked
+    lo, hi = [0, 40, 45], [40, 45, 110]
+    acc = (np.arange(110) % 3 == 0).astype(np.uint8)
+    sw = (65 + 31) // 32
+    gathered = np.full((3, sw), 0xFFFFFFFF, np.uint32)
+    for r in range(3):
+        bits = np.zeros(sw * 32, np.uint8)
+        bits[: hi[r] - lo[r]] = acc[lo[r]:hi[r]]
+        bits[hi[r] - lo[r]:] = 1                                                    # stale words a careless producer left
+        gathered[r] = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+    a2, bm = rsv.exchange_assemble(110, 3, gathered, plan=(lo, hi))
+    assert a2.tolist() == acc.tolist() and np.array_equal(np.unpackbits(bm.view(np.uint8), bitorder="little")[:110], acc)
+    with pytest.raises(rsv.RsvError):
+        rsv.exchange_assemble(110, 3, gathered, plan=([0, 41, 45], hi))             # not contiguous
 
 
 def test_poseidon_flow_count_is_host_arithmetic(rsv):

@@ -91,7 +91,8 @@ def test_bench_launches_its_own_ranks():
 def test_bench_total_proofs_strong_scaling():
     d = _bench(["--gpus", "2", "--rehearsal", "--total-proofs", "4099", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 4099
-    assert d["config"]["proofs_rank0"] == 2050
+    assert abs(d["config"]["proofs_rank0"] - 2050) <= 2 and "rsv_shard_plan" in d["config"]["partition"]   # cut by bytes: the round-robin mix is uniform
+    assert len(d["config"]["shard_bytes"]) == 2 and max(d["config"]["shard_bytes"]) / min(d["config"]["shard_bytes"]) < 1.01
     d1 = _bench(["--total-proofs", "3000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
     assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["proofs_rank0"] == 3000
 
@@ -272,6 +273,85 @@ def test_bench_three_rank_rehearsal_odd_split():
     ranks on cuda:0 (gloo exchange) with a job that does not divide: 3 001 proofs -> shards of 1 001 / 1 000 / 1 000.
     World 8 with an odd split (and with more ranks than proofs) runs on the CPU in tests/test_sharding.py."""
     d = _bench(["--gpus", "3", "--rehearsal", "--total-proofs", "3001", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
-    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 3001 and d["config"]["proofs_rank0"] == 1001
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 3001 and abs(d["config"]["proofs_rank0"] - 1001) <= 2
     ex = d["config"]["exchange"]
     assert ex["world_size"] == 3 and sorted(x["rank"] for x in ex["devices"]) == [0, 1, 2] and len({x["pid"] for x in ex["devices"]}) == 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VERDICT r4 (missing 3-5): a work-balanced partition, and the C-ABI's multi-GPU paths under bench.py's clock.
+def test_multi_host_level_ordered_chain(rsv):
+    """The reference's job arrives ordered by level (435 KB / 80-query proofs first): rsv_multi_verify_batch_host cuts it by
+    bytes (rsv_shard_plan).  Three contexts on cuda:0, 13 shapes x 6 copies in level order with tampered copies: verdicts and
+    reasons == the oracle's; the plan over the same lengths is balanced where equal counts are not."""
+    import numpy as np
+    from tests import oracle_binding as ob
+    from tests.conftest import fixture_cfg, read_proof
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+             "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]
+    proofs, cfgs = [], []
+    for k, nm in enumerate(names):
+        for c in range(6):
+            pr = read_proof(nm)
+            proofs.append(ob.tamper(pr, 11 * k + c) if c % 3 == 1 else pr)
+            cfgs.append(fixture_cfg(nm))
+    lens = np.array([len(p) for p in proofs], np.uint64)
+    lo, hi = rsv.shard_plan(lens, 3)
+    pre = np.concatenate([[0], np.cumsum(lens)])
+    planned = [int(pre[h] - pre[l]) for l, h in zip(lo, hi)]
+    counted = [int(pre[h] - pre[l]) for l, h in (rsv.shard_range(len(proofs), r, 3) for r in range(3))]
+    assert max(planned) / min(planned) < 1.35 < max(counted) / min(counted)   # (78 proofs: one 435 KB proof is 3 % of a shard)
+    mc = rsv.MultiContext([0, 0, 0])
+    acc, reason, bitmap, count = mc.verify_batch_host(proofs, cfgs)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
+    assert np.array_equal(acc, oacc) and np.array_equal(reason, oreason) and count == int(oacc.sum()) and 30 < count < 60
+    mc.close()
+
+
+def test_bench_c_abi_exchange_and_one_process_lines():
+    """`bench.py --exchange c` (rsv_exchange_create / run: the library's own ncclAllGather + ncclAllReduce on the verifier's
+    stream) at world 1 and `bench.py --devices 0` / `--devices 0,0` (rsv_multi_verify_batch_dev, host-assembled bitmap): each
+    prints the standard line, and each has checked the whole job's accept map against the same tamper rule as the default
+    line (bench.py exits non-zero otherwise) — the three paths give the same verdicts."""
+    common = ["--proofs", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0", "--no-single-proof"]
+    d0 = _bench(common, {})
+    dc = _bench(common + ["--exchange", "c"], {})
+    dm = _bench(common + ["--devices", "0"], {})
+    assert d0["config"]["exchange"]["backend"].startswith("torch")
+    assert dc["config"]["exchange"]["backend"].startswith("rsv_exchange (rccl ") and dc["value"] > 0 and dc["roofline"]["kernel_ms"] > 0
+    assert dm["config"]["exchange"]["backend"] == "rsv_multi (host assembly)" and dm["value"] > 0 and dm["n_gpus"] == 1
+    assert d0["config"]["proofs_per_step"] == dc["config"]["proofs_per_step"] == dm["config"]["proofs_per_step"] == 2048
+    # the level-ordered chain as a job of fixed size over two contexts of one process: cut by bytes
+    dl = _bench(["--devices", "0,0", "--workload", "chain", "--order", "level", "--total-proofs", "1300", "--steps", "1", "--warmup", "1"], {})
+    sb = dl["config"]["shard_bytes"]
+    assert dl["scaling"] == "strong" and "rsv_shard_plan" in dl["config"]["partition"] and max(sb) / min(sb) < 1.02
+    # ... and through the per-rank path with the C exchange (one rank: the plan is the whole job)
+    dr = _bench(["--exchange", "c", "--workload", "chain", "--order", "level", "--total-proofs", "1300", "--steps", "1", "--warmup", "1",
+                 "--cpu-sample", "0", "--perm-log2", "0", "--no-single-proof"], {})
+    assert dr["config"]["order"] == "level" and dr["config"]["proofs_rank0"] == 1300
+
+
+def _n_devices():
+    try:
+        import rsvload
+        return rsvload.load_package().device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two HIP devices (this pool's boxes have one: the path is covered on one device above)")
+def test_two_physical_devices_multi_and_exchange(rsv):
+    """the multi-GPU C-ABI in the configuration it exists for.  rsv_multi on devices {0, 1} against the oracle, and
+    a 2-rank rsv_exchange (bench.py --gpus 2 --exchange c) over an uneven split — 65 proofs: rank 1's slice is narrower than
+    the all-gather's slice_words, the words in between must arrive as zeros."""
+    import numpy as np
+    from tests import oracle_binding as ob
+    proofs, cfgs = _mixed_job(ob, 130)
+    mc = rsv.MultiContext([0, 1])
+    acc, reason, bitmap, count = mc.verify_batch_host(proofs, cfgs)
+    oacc, oreason = ob.verify_batch(proofs, cfgs)
+    assert np.array_equal(acc, oacc) and np.array_equal(reason, oreason) and count == int(oacc.sum())
+    mc.close()
+    d = _bench(["--gpus", "2", "--exchange", "c", "--total-proofs", "65", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--perm-log2", "0"], {})
+    assert d["n_gpus"] == 2 and d["config"]["exchange"]["backend"].startswith("rsv_exchange (rccl ") and d["config"]["proofs_per_step"] == 65
+    assert len({x["uuid"] for x in d["config"]["exchange"]["devices"]}) == 2

@@ -20,7 +20,16 @@ def load_sharding():
     return sh
 
 
-def _worker(rank, world, port, n_total, q):
+def _plan_for(sh, n_total, world, planned):
+    """planned: a byte-balanced plan over synthetic lengths that fall off steeply (the level-ordered chain in small), so that
+    the shards are of very unequal COUNT: the widest slice sets slice_words, the narrow ones leave most of theirs zero."""
+    if not planned:
+        return None
+    lens = [4000 // (1 + i // 3) + 7 for i in range(n_total)]
+    return sh.shard_plan(lens, world)
+
+
+def _worker(rank, world, port, n_total, q, planned=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -32,7 +41,8 @@ def _worker(rank, world, port, n_total, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     proof = read_proof("small_proof.bin")
-    ex = sh.BitmapExchange(n_total, rank, world, dist, torch, torch.device("cpu"))
+    plan = _plan_for(sh, n_total, world, planned)
+    ex = sh.BitmapExchange(n_total, rank, world, dist, torch, torch.device("cpu"), plan=plan)
     batch = [ob.tamper(proof, i) if i % 5 == 2 else proof for i in range(ex.lo, ex.hi)]
     acc, _ = ob.verify_batch(batch, ob.PcsConfig(20, 5, 2, 16), [(1, (1, 0, 0, 0))])
     bits = sh.pack_bitmap(acc).view(np.int32)
@@ -44,7 +54,7 @@ def _worker(rank, world, port, n_total, q):
         ex.run()
         results.append((ex.assemble().tolist(), ex.total_accepted()))
     # the functional form on the same group
-    full = sh.gather_accept_bitmap(torch.from_numpy(bits.copy()), n_total, rank, world, dist, torch)
+    full = sh.gather_accept_bitmap(torch.from_numpy(bits.copy()), n_total, rank, world, dist, torch, plan=plan)
     q.put((rank, results, full.tolist()))
     dist.destroy_process_group()
 
@@ -98,15 +108,49 @@ def test_launcher_command_line(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_shard_plan_restatement_and_balance():
+    """sharding.shard_plan (Python) == rsv_shard_plan (the C entry point, host arithmetic: no device needed) on random and
+    degenerate jobs; and the property it exists for: on the reference's chain in LEVEL order (13 x 4 096 proofs, 435 KB
+    down to 76 KB) over 8 ranks the heaviest shard carries <= 1.1 x the lightest's bytes (by count: 4.5 x)."""
+    sys.path.insert(0, ROOT)
+    import rsvload
+    rsv = rsvload.load_package()
+    sh = load_sharding()
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        n = int(rng.integers(0, 400))
+        world = int(rng.integers(1, 12))
+        lens = rng.integers(0, 500000, n) if trial % 3 else np.repeat(rng.integers(1, 500000, 5), 80)[:n]
+        assert sh.shard_plan(lens, world) == rsv.shard_plan(lens.astype(np.uint64), world), (trial, n, world)
+    from tests.conftest import read_proof
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+             "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]
+    lens = np.repeat([len(read_proof(nm)) for nm in names], 4096)
+    lo, hi = sh.shard_plan(lens, 8)
+    pre = np.concatenate([[0], np.cumsum(lens)])
+    b = [int(pre[h] - pre[l]) for l, h in zip(lo, hi)]
+    assert max(b) / min(b) <= 1.1 and max(h - l for l, h in zip(lo, hi)) > 2 * min(h - l for l, h in zip(lo, hi))
+    with pytest.raises(ValueError):
+        import torch
+        import torch.distributed as dist
+        sh.BitmapExchange(70, 0, 1, dist, torch, torch.device("cpu"), plan=([0], [69]))  # a plan covers the whole job
+
+
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("n_total,world", [(23, 2), (64, 2), (7, 3), (83, 8), (5, 8)])
-def test_gloo_ranks_bitmap_exchange(n_total, world):
+@pytest.mark.parametrize("n_total,world,planned", [(23, 2, False), (64, 2, False), (7, 3, False), (83, 8, False), (5, 8, False),
+                                                   (83, 8, True), (65, 2, True), (40, 3, True)])
+def test_gloo_ranks_bitmap_exchange(n_total, world, planned):
+    """planned: the job cut by shard_plan over lengths that fall off steeply — slices of very unequal width (83 proofs over 8
+    ranks: 3 ... 40 proofs), every rank sending the widest slice's words."""
     import torch.multiprocessing as mp
     sh = load_sharding()
+    if planned:
+        lo, hi = _plan_for(sh, n_total, world, True)
+        assert max(h - l for l, h in zip(lo, hi)) >= 3 * max(1, min(h - l for l, h in zip(lo, hi)))
     ctx = mp.get_context("spawn")
     port = sh.free_port()
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, planned)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=200) for _ in range(world)]

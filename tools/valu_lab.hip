@@ -1,6 +1,11 @@
 // valu_lab.hip — instruction-throughput microbenchmarks for the integer VALU ops the Poseidon2
 // permutation is made of (MI355X / gfx950).  Build: hipcc --offload-arch=gfx950 -O3 -o valu_lab valu_lab.hip
-// Prints wave-instruction issue cycles per SIMD assuming every SIMD holds WAVES waves.
+// Prints wave-instruction issue cycles per SIMD assuming every SIMD holds WAVES waves — twice (VERDICT r4 #5b):
+//   wall-normalised   launch time (HIP events) x 2.4 GHz / wave-instructions per SIMD: what a step's wall time pays
+//   shader cycles     clock64() (s_memtime: the shader clock) around each wave's loop / wave-instructions per SIMD
+// and the clock the two imply (shader cycles of a wave / the launch's wall time).  "2.5 cycles" wall-normalised is
+// 2.0 real cycles at 1.92 GHz or 2.5 real cycles at 2.4 GHz: the two columns tell which.  rocprofv3 --pmc GRBM_GUI_ACTIVE
+// on this binary gives the same clock from the outside (tools/lab.sh).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -15,9 +20,12 @@
         uint32_t b = seed | 1u, c = seed + 12345u;                                                   \
         uint64_t w[CHAINS];                                                                          \
         for (int i = 0; i < CHAINS; i++) { a[i] = threadIdx.x * 2654435761u + i + seed; w[i] = a[i]; } \
+        const long long t0_ = clock64();                                                             \
         for (int it = 0; it < ITERS; it++) {                                                         \
             _Pragma("unroll") for (int i = 0; i < CHAINS; i++) { ASM_LINE; }                         \
         }                                                                                            \
+        const long long t1_ = clock64();                                                             \
+        if ((threadIdx.x & 63u) == 0) ((long long*)out)[8 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1_ - t0_; \
         uint32_t r = 0;                                                                              \
         for (int i = 0; i < CHAINS; i++) r ^= a[i] ^ (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);         \
         if (r == 0x12345678u) out[0] = r;                                                            \
@@ -157,9 +165,12 @@ DEF_KERNEL(k_chain_nop, asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %1, 0\n\ts
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {                      \
         uint32_t a = threadIdx.x * 2654435761u + seed, b = seed | 1u;                                \
         uint64_t w = a;                                                                              \
+        const long long t0_ = clock64();                                                             \
         for (int it = 0; it < ITERS; it++) {                                                         \
             _Pragma("unroll") for (int i = 0; i < CHAINS; i++) { BODY; }                             \
         }                                                                                            \
+        const long long t1_ = clock64();                                                             \
+        if ((threadIdx.x & 63u) == 0) ((long long*)out)[8 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1_ - t0_; \
         if ((a ^ (uint32_t)w ^ (uint32_t)(w >> 32)) == 0x12345678u) out[0] = a;                      \
     }
 DEF_DEP(d_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)))
@@ -184,7 +195,9 @@ struct Case { const char* name; kern_t k; };
 int main(int argc, char** argv) {
     int waves_per_simd = argc > 1 ? atoi(argv[1]) : 4;
     uint32_t* out;
-    hipMalloc(&out, 4096);
+    const size_t out_bytes = 64 + 8 * 4 * 256 * 8 * 2;  // [8 ..): shader cycles of every wave's loop (kernels of the two macros)
+    hipMalloc(&out, out_bytes);
+    std::vector<long long> clk((out_bytes - 64) / 8);
     Case cases[] = {{"v_add_u32", k_add}, {"v_add3_u32", k_add3}, {"v_min_u32", k_min}, {"v_and_b32", k_and},
                     {"v_alignbit_b32", k_alignbit}, {"v_and_or_b32", k_and_or}, {"v_lshl_add_u32", k_lshl_add},
                     {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi}, {"v_mul_u32_u24", k_mul_u24},
@@ -216,9 +229,11 @@ int main(int argc, char** argv) {
     printf("CUs %d, clock %d kHz, %d waves/SIMD\n", cus, prop.clockRate, waves_per_simd);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-38s %9s %12s %12s %10s\n", "instruction", "ms", "cyc@2.4(wall)", "cyc(shader)", "clock GHz");
     for (auto& c : cases) {
         hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1u);
         hipDeviceSynchronize();
+        hipMemset(out, 0, out_bytes);
         hipEventRecord(e0);
         for (int r = 0; r < 5; r++) hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1u + r);
         hipEventRecord(e1);
@@ -227,7 +242,16 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&ms, e0, e1);
         double insts_per_simd = 5.0 * waves_per_simd * (double)ITERS * CHAINS;  // wave-instructions per SIMD
         double ns_per_inst = ms * 1e6 / insts_per_simd;
-        printf("%-22s %8.3f ms  %6.3f ns/wave-inst/SIMD  = %5.2f cycles @2.4GHz\n", c.name, ms, ns_per_inst, ns_per_inst * 2.4);
+        // shader cycles of the waves' loops (last launch): a wave shares its SIMD with waves_per_simd - 1 others for the whole loop
+        hipMemcpy(clk.data(), (char*)out + 64, (size_t)blocks * 4 * 8, hipMemcpyDeviceToHost);
+        double sum = 0; size_t cnt = 0;
+        for (size_t k = 0; k < (size_t)blocks * 4; k++) if (clk[k] > 0) { sum += (double)clk[k]; cnt++; }
+        if (cnt) {
+            const double wave_cycles = sum / cnt;
+            const double cyc_shader = wave_cycles / ((double)ITERS * CHAINS * waves_per_simd);   // per wave-instruction per SIMD
+            const double ghz = wave_cycles / (ms / 5.0 * 1e6);                                   // shader cycles per ns of one launch
+            printf("%-38s %9.3f %12.2f %12.2f %10.3f\n", c.name, ms, ns_per_inst * 2.4, cyc_shader, ghz);
+        } else printf("%-38s %9.3f %12.2f %12s %10s\n", c.name, ms, ns_per_inst * 2.4, "-", "-");
     }
     return 0;
 }
