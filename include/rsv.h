@@ -173,7 +173,7 @@ typedef enum rsv_option {
     RSV_OPT_TREE_CAP = 6,         /* 0 / 1 dense top-of-tree cap, 2 every lane walks its path to the root */
     RSV_OPT_OVERLAP_TREES = 7,    /* 0 auto, 1 FRI trees beside the trace trees (single-group batches), 2 behind them */
     RSV_OPT_WS_BUDGET_MB = 8,     /* 1 .. 2^20: budget of the per-query workspace (default 8192); larger batches are cut into groups */
-    RSV_OPT_PERM_WG_PER_CU = 9,   /* 1 .. 8: grid of the persistent rsv_poseidon2_permute kernel (default 8) */
+    RSV_OPT_PERM_WG_PER_CU = 9,   /* 1 .. 32: workgroups per CU of the grid-stride rsv_poseidon2_permute kernel (default 24) */
     RSV_OPT_HOST_CHUNK_MB = 10,   /* 1 .. 16384: staging chunk of rsv_verify_batch_host (default 256) */
     RSV_OPT_HOST_THREADS = 11,    /* 0 = min(cores, 4), else 1 .. 64 gather threads of rsv_verify_batch_host */
     RSV_OPT_DEBUG_LOG = 12,       /* 0 / 1: print failing HIP calls to stderr (process-wide, ctx ignored) */
@@ -208,6 +208,8 @@ typedef enum rsv_option {
     RSV_OPT_CAP_MID = 26,         /* with the cap's top in kernels of its own (RSV_OPT_CAP_TOP): 0 auto — a bucket of proofs whose dense cap levels
                                      fill the tree kernels' waves badly (80, 27, 11, 10 queries) hands its nodes over at the cap level, a
                                      lane per subtree walks the middle levels (k_cap_mid), k_cap_top the rest; 1 every bucket does, 2 none */
+    RSV_OPT_PERM_FORM = 27,       /* rsv_poseidon2_permute_dev, experiments: 0 production (the out-of-line instance the verify kernels call), 1 the same
+                                     inlined, 2 inlined without wait states (recursive-stwo_amd/csrc/primitives.hpp: k_permute) */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -14,7 +14,11 @@ namespace rsv {
 // launch + first-touch latency per single permutation (7.97 -> 8.83 G permutations/s on 2^24 states).  Measured and
 // rejected: a tile-per-wave variant with fully coalesced 1 KB global accesses and an LDS transpose (8.59 G/s): the
 // kernel is VALU-issue bound, the 16-byte-per-lane accesses at 64-byte stride cost nothing that shows.
-__global__ __launch_bounds__(256) void k_permute(const uint4* __restrict__ in, uint4* __restrict__ out,
+// FORM (RSV_OPT_PERM_FORM, an experiment's knob; 0 = what production runs): 0 the out-of-line paced instance the verify
+// kernels call, 1 the same inlined (+0.2 % at 24 workgroups per CU, +2 % at 6), 2 inlined without the wait states (-4 %);
+// WAVES: the launch bound (the kernel takes 62-66 registers whatever it says).
+template <int FORM = 0, int WAVES = 1>
+__global__ __launch_bounds__(256, WAVES) void k_permute(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                  size_t n, uint32_t* __restrict__ bad) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,7 +40,9 @@ __global__ __launch_bounds__(256) void k_permute(const uint4* __restrict__ in, u
 #pragma unroll
             for (int k = 0; k < 4; k++) nx[k] = in[4 * next + k];
         }
-        st = poseidon2(st);  // the single out-of-line instance the verify kernels call
+        if constexpr (FORM == 0) st = poseidon2(st);  // the single out-of-line instance the verify kernels call
+        else if constexpr (FORM == 1) PermT<true>::poseidon2_inline(st.s);
+        else PermT<false>::poseidon2_inline(st.s);
 #pragma unroll
         for (int k = 0; k < 4; k++) out[4 * i + k] = make_uint4(st.s[4 * k], st.s[4 * k + 1], st.s[4 * k + 2], st.s[4 * k + 3]);
         if (next >= n) break;

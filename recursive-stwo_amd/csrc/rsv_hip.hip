@@ -39,7 +39,8 @@ struct Options {
     int tree_cap = 0;          // 0 / 1 dense top-of-tree cap, 2 every path walks to the root
     int overlap_trees = 0;     // 0 / 1 FRI trees beside the trace trees, 2 behind them
     long long ws_budget_mb = 8192;
-    int perm_wg_per_cu = 8;
+    int perm_wg_per_cu = 24;
+    int perm_form = 0;         // experiment: instance / launch bound of k_permute (primitives.hpp)
     long long host_chunk_mb = 256;
     int host_threads = 0;      // 0 = min(cores, 4)
     int critical_chain = 0;    // 0 auto, 1 the chain of dependent kernels on ONE stream, 2 the round-2 stream layout
@@ -130,9 +131,11 @@ Options default_options() {
 
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-// k_permute is persistent: enough 256-thread workgroups to fill every SIMD of the device at the kernel's occupancy
-// (RSV_OPT_PERM_WG_PER_CU workgroups per CU; default 8 = twice what is resident, which evens out the tail: measured
-// 7.7 / 8.3 / 8.6 / 8.8 / 8.3 G permutations/s at 2 / 4 / 6 / 8 / 16), never more than one lane per state
+// k_permute walks the states with a grid stride from a grid sized to the machine, not to n: RSV_OPT_PERM_WG_PER_CU workgroups
+// of 256 lanes per CU (8 are resident at the kernel's 64 registers).  Measured on 2^24 states (tools/perm_bench.py, round 5:
+// gpurun_out/r5_h/perm.txt): 8.85 / 9.20 / 9.38 / 9.46 / 9.58 / 9.75 G permutations/s at 6 / 8 / 10 / 12 / 16 / 24 — with
+// exactly the resident number every lane walks the same count and the launch ends on its slowest wave; three times as many,
+// a third as long each, even that out (default 24; until round 4: 8, 8.83 G/s on that round's boxes).  Never more than one lane per state.
 inline unsigned permute_grid(size_t n, int wg_per_cu) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -271,8 +274,11 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_WS_BUDGET_MB:
             if (value < 1 || value > (1ll << 20)) return RSV_E_RANGE;
             o.ws_budget_mb = value; return RSV_OK;
+        case RSV_OPT_PERM_FORM:
+            if (value < 0 || value > 2) return RSV_E_RANGE;
+            o.perm_form = (int)value; return RSV_OK;
         case RSV_OPT_PERM_WG_PER_CU:
-            if (value < 1 || value > 8) return RSV_E_RANGE;
+            if (value < 1 || value > 32) return RSV_E_RANGE;
             o.perm_wg_per_cu = (int)value; return RSV_OK;
         case RSV_OPT_HOST_CHUNK_MB:
             if (value < 1 || value > 16384) return RSV_E_RANGE;
@@ -311,8 +317,16 @@ int rsv_poseidon2_permute_dev(rsv_ctx* c, const uint32_t* d_in, uint32_t* d_out,
     if (n > ((size_t)1 << 31)) return RSV_E_SIZE;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return RSV_E_SIZE;
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n, c->opt.perm_wg_per_cu)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint4*>(d_in), reinterpret_cast<uint4*>(d_out), n, d_bad);
+    {
+        const dim3 grid(permute_grid(n, c->opt.perm_wg_per_cu));
+        const uint4* pin = reinterpret_cast<const uint4*>(d_in);
+        uint4* pout = reinterpret_cast<uint4*>(d_out);
+        switch (c->opt.perm_form) {  // RSV_OPT_PERM_FORM: an experiment's knob
+            case 1: hipLaunchKernelGGL((k_permute<1, 1>), grid, dim3(256), 0, c->stream, pin, pout, n, d_bad); break;
+            case 2: hipLaunchKernelGGL((k_permute<2, 1>), grid, dim3(256), 0, c->stream, pin, pout, n, d_bad); break;
+            default: hipLaunchKernelGGL((k_permute<0, 1>), grid, dim3(256), 0, c->stream, pin, pout, n, d_bad); break;
+        }
+    }
     HIP_TRY(hipGetLastError());
     return RSV_OK;
 }
@@ -329,7 +343,7 @@ int rsv_poseidon2_permute(const uint32_t* in16, uint32_t* out16, size_t n, int d
     HIP_TRY(dbad.alloc(4));
     HIP_TRY(hipMemset(dbad.p, 0, 4));
     HIP_TRY(hipMemcpy(din.p, in16, 64 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_permute, dim3(permute_grid(n, default_options().perm_wg_per_cu)), dim3(256), 0, 0, din.as<const uint4>(),
+    hipLaunchKernelGGL((k_permute<0, 1>), dim3(permute_grid(n, default_options().perm_wg_per_cu)), dim3(256), 0, 0, din.as<const uint4>(),
                        dout.as<uint4>(), n, dbad.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     uint32_t bad = 0;

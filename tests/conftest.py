@@ -88,7 +88,7 @@ class _Knobs:
     """Process-default tuning knobs of the product library (rsv_ctx_set_option with ctx = NULL), restored to
     "automatic" when the test ends.  The library never reads the environment."""
 
-    DEFAULTS = {"ws_budget_mb": 8192, "perm_wg_per_cu": 8, "host_chunk_mb": 256}
+    DEFAULTS = {"ws_budget_mb": 8192, "perm_wg_per_cu": 24, "host_chunk_mb": 256}
 
     def __init__(self, rsv):
         self.rsv, self.touched = rsv, set()

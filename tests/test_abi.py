@@ -79,7 +79,7 @@ def test_options_are_explicit_and_validated(rsv):
             assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], v) == 0, name
     for v, want in ((4, -5), (-1, -5), (3, 0), (2, 0), (1, 0), (0, 0)):  # four settings: auto, paced, unpaced, row form
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS["tree_pace"], v) == want, v
-    for name, bad, good in (("ws_budget_mb", 0, 8192), ("perm_wg_per_cu", 9, 8), ("host_chunk_mb", 0, 256), ("host_threads", 65, 0),
+    for name, bad, good in (("ws_budget_mb", 0, 8192), ("perm_wg_per_cu", 33, 24), ("host_chunk_mb", 0, 256), ("host_threads", 65, 0),
                             ("debug_log", 2, 0), ("witness_small_max", (1 << 20) + 2, 0), ("witness_small_log", 8, 0), ("witness_walk_log", 8, 0)):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], bad) == -5, name
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], good) == 0, name

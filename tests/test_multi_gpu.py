@@ -84,7 +84,7 @@ def test_bench_launches_its_own_ranks():
     ex = d["config"]["exchange"]
     assert d["config"]["proofs_per_step"] == 4096 and d["value"] > 0 and "gloo" in ex["collectives"]
     # the line proves from inside the group that two ranks took part (here: two processes on the one device)
-    assert ex["world_size"] == 2 and ex["backend"] == "gloo" and sorted(x["rank"] for x in ex["devices"]) == [0, 1]
+    assert ex["world_size"] == 2 and ex["backend"] == "torch.distributed (gloo)" and sorted(x["rank"] for x in ex["devices"]) == [0, 1]
     assert len({x["pid"] for x in ex["devices"]}) == 2
 
 

@@ -19,7 +19,8 @@ gen.manual_seed(1)
 d_in = torch.randint(0, 0x7FFFFFFF, (m, 16), dtype=torch.int32, device=dev, generator=gen)
 d_out = torch.empty_like(d_in)
 ctx = rsv.Context(0)
-for wg in os.environ.get("PERM_WG_LIST", "4").split(","):
+for form, wg in [(f, w) for f in os.environ.get("PERM_FORM_LIST", "0").split(",") for w in os.environ.get("PERM_WG_LIST", "24").split(",")]:
+    ctx.set_option("perm_form", int(form))
     ctx.set_option("perm_wg_per_cu", int(wg))
     ctx.poseidon2_permute(d_in, d_out)
     ctx.synchronize()
@@ -30,4 +31,4 @@ for wg in os.environ.get("PERM_WG_LIST", "4").split(","):
             ctx.poseidon2_permute(d_in, d_out)
         ctx.synchronize()
         best = min(best, (time.perf_counter() - t0) / 5)
-    print(f"wg_per_cu={wg}: {m / best / 1e9:.3f} G perms/s, {m * 128 / best / 1e9:.0f} GB/s")
+    print(f"form={form} wg_per_cu={wg}: {m / best / 1e9:.3f} G perms/s, {m * 128 / best / 1e9:.0f} GB/s")
