@@ -210,6 +210,8 @@ typedef enum rsv_option {
                                      lane per subtree walks the middle levels (k_cap_mid), k_cap_top the rest; 1 every bucket does, 2 none */
     RSV_OPT_PERM_FORM = 27,       /* rsv_poseidon2_permute_dev, experiments: 0 production (the out-of-line instance the verify kernels call), 1 the same
                                      inlined, 2 inlined without wait states (recursive-stwo_amd/csrc/primitives.hpp: k_permute) */
+    RSV_OPT_OODS_EARLY = 28,      /* chain layout, experiments: 0 / 2 the OODS check behind the trace trees on the side stream; 1 on a third
+                                     stream right behind the transcript (measured: slower from 1 024 to 4 096 proofs, not taken) */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -12,7 +12,14 @@ struct EvalCtx {
     QM31 fp[5], fq[5];
     const uint32_t* w;
     int inter;  // next interaction sample index
-    __device__ QM31 smp(int k) const { return ldq(w + SAMPLES.off[k]); }
+    uint32_t prefix_diff = 0;  // OR of (word ^ expected) over the sample-count prefixes passed so far (bincode shape: k_parse.hpp)
+    // a sampled value, and — with the first sample of a column — the column's u64 sample-count prefix in front of it (the same
+    // cache line): the evaluation reads all 142 samples, so it passes all 134 column prefixes
+    __device__ QM31 smp(int k) {
+        const uint32_t po = SAMPLES.pre_of[k];
+        if (po) prefix_diff |= (w[po] ^ (uint32_t)SAMPLES.cnt_of[k]) | w[po + 1];
+        return ldq(w + SAMPLES.off[k]);
+    }
     // data_structures.rs:26-28,166-169
     __device__ void constraint(QM31 v) { acc = q_add(q_mul(acc, rc), q_mul(v, dinv)); }
     // data_structures.rs:147-164.  K (the fraction's index) and the batch geometry below are compile-time constants so
@@ -76,7 +83,7 @@ struct QState {
         base[(4 * i) * 64] = v.a.a; base[(4 * i + 1) * 64] = v.a.b; base[(4 * i + 2) * 64] = v.b.a; base[(4 * i + 3) * 64] = v.b.b;
     }
 };
-constexpr int QSTATE_WORDS = 16 * 4 * 64;  // per workgroup of 64 lanes
+constexpr int QSTATE_WORDS = 3 * 16 * 4 * 64;  // per workgroup of 64 lanes: the round state, and the 16 `in` and 16 `out` samples
 // poseidon.rs:12-71 over QM31
 __device__ inline void q_m4(QState s, int g) {
     const QM31 x0 = s.get(g), x1 = s.get(g + 1), x2 = s.get(g + 2), x3 = s.get(g + 3);
@@ -108,9 +115,12 @@ __device__ __noinline__ void q_internal(QState s) {
 // The 86-constraint accumulator and the value it must equal (composition/src/lib.rs:60-120) for one proof whose
 // sampled values sit at their fixed word offsets behind `w`.  Shared by k_oods and by the probe k_oods_probe
 // (rsv_oods_eval), so that the evaluation can be checked on its own, on arbitrary samples.
-// st: this lane's QState (LDS of the calling kernel: QSTATE_WORDS words per 64 lanes).
+// st: this lane's QState (LDS of the calling kernel: QSTATE_WORDS words per 64 lanes).  Behind the round state the same LDS
+// keeps the 16 input and 16 output words of the Poseidon row, which the constraints visit four times each: 65 536 lanes
+// hold 223 MB of sampled values between them, so a line left for a moment is gone from the L2 when its lane comes back
+// (round 5: 0.78 GB of traffic with one global read per visit).
 __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32_t lq, QM31 plonk_sum, QM31 poseidon_sum, QM31 z,
-                                 QM31 alpha, QM31 rc, QM31 ox, QState st, QM31& acc_out, QM31& expected_out) {
+                                 QM31 alpha, QM31 rc, QM31 ox, QState st, QM31& acc_out, QM31& expected_out, uint32_t& prefix_diff_out) {
     EvalCtx e;
     e.rc = rc; e.acc = q_zero(); e.z = z; e.alpha = alpha; e.alpha2 = q_mul(alpha, alpha); e.w = w;
     const QM31 one = q_one();
@@ -142,18 +152,21 @@ __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32
         QM31 is_first = e.smp(pre), is_last = e.smp(pre + 1), is_full = e.smp(pre + 2), round_id = e.smp(pre + 3);
         QM31 not_first = q_sub(one, is_first), not_last = q_sub(one, is_last), is_partial = q_sub(not_first, is_full);
         QM31 swap_val = e.smp(mid), one_minus_swap = q_sub(one, swap_val);
+        const QState inq{st.base + 16 * 4 * 64}, outq{st.base + 2 * 16 * 4 * 64};
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) { inq.set(i, e.smp(in + i)); outq.set(i, e.smp(out + i)); }  // the one global read of each
 #pragma unroll 1
         for (int i = 0; i < 16; i++) {
-            QM31 lo = e.smp(in + (i & 7)), hi = e.smp(in + (i & 7) + 8);
+            QM31 lo = inq.get(i & 7), hi = inq.get((i & 7) + 8);
             st.set(i, i < 8 ? q_add(q_mul(lo, one_minus_swap), q_mul(hi, swap_val))
                             : q_add(q_mul(lo, swap_val), q_mul(hi, one_minus_swap)));
         }
         q_external(st);
 #pragma unroll 1
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_first, q_sub(st.get(i), e.smp(out + i))));
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_first, q_sub(st.get(i), outq.get(i))));
 #pragma unroll 1
         for (int i = 0; i < 16; i++) {
-            QM31 full = q_pow5(q_add(e.smp(in + i), e.smp(rc0 + i)));
+            QM31 full = q_pow5(q_add(inq.get(i), e.smp(rc0 + i)));
             QM31 mi = e.smp(mid + i);
             e.constraint(q_mul(is_full, q_sub(mi, full)));
             st.set(i, mi);
@@ -163,9 +176,9 @@ __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32
         for (int i = 0; i < 16; i++) st.set(i, q_pow5(q_add(st.get(i), e.smp(rc1 + i))));
         q_external(st);
 #pragma unroll 1
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_full, q_sub(e.smp(out + i), st.get(i))));
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_full, q_sub(outq.get(i), st.get(i))));
 #pragma unroll 1
-        for (int i = 0; i < 16; i++) st.set(i, e.smp(in + i));
+        for (int i = 0; i < 16; i++) st.set(i, inq.get(i));
 #pragma unroll 1
         for (int r = 0; r < 14; r++) {
             QM31 v = q_pow5(q_add(st.get(0), e.smp(rc0 + r)));
@@ -175,19 +188,19 @@ __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32
             q_internal(st);
         }
 #pragma unroll 1
-        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_partial, q_sub(e.smp(out + i), st.get(i))));
+        for (int i = 0; i < 16; i++) e.constraint(q_mul(is_partial, q_sub(outq.get(i), st.get(i))));
         QM31 ext1 = e.smp(pre + 36), ext2 = e.smp(pre + 37), ext1_nz = e.smp(pre + 38), ext2_nz = e.smp(pre + 39);
         QM31 in_left = q_dbl(round_id), in_right = q_add(in_left, one), out_left = q_add(in_right, one),
              out_right = q_add(out_left, one);
-#define EF4(base) q_combine_ef(e.smp(base), e.smp((base) + 1), e.smp((base) + 2), e.smp((base) + 3))
+#define EF4(q, k) q_combine_ef(q.get(k), q.get((k) + 1), q.get((k) + 2), q.get((k) + 3))
         e.relation<0>(q_sub(q_mul(ext1_nz, is_first), not_first), q_add(q_mul(is_first, ext1), q_mul(not_first, in_left)),
-                   EF4(in), EF4(in + 4));
+                   EF4(inq, 0), EF4(inq, 4));
         e.relation<1>(q_sub(q_mul(ext2_nz, is_first), not_first), q_add(q_mul(is_first, ext2), q_mul(not_first, in_right)),
-                   EF4(in + 8), EF4(in + 12));
+                   EF4(inq, 8), EF4(inq, 12));
         e.relation<2>(q_add(q_mul(ext1_nz, is_last), not_last), q_add(q_mul(is_last, ext1), q_mul(not_last, out_left)),
-                   EF4(out), EF4(out + 4));
+                   EF4(outq, 0), EF4(outq, 4));
         e.relation<3>(q_add(q_mul(ext2_nz, is_last), not_last), q_add(q_mul(is_last, ext2), q_mul(not_last, out_right)),
-                   EF4(out + 8), EF4(out + 12));
+                   EF4(outq, 8), EF4(outq, 12));
 #undef EF4
         e.relation<4>(q_mul(is_first, not_last), swap_val, e.smp(rc0));
         e.finalize_logup<5, 3>();
@@ -199,7 +212,35 @@ __device__ __forceinline__ void oods_eval(const uint32_t* w, uint32_t lp, uint32
         expected_out = q_add(left, q_mul(right, q_double_x(ox, bound - 2)));
     }
     acc_out = e.acc;
+    prefix_diff_out = e.prefix_diff;
 }
+
+// the u64 column-count prefixes of the four trees of sampled_values (the column prefixes: EvalCtx::smp / prefix_diff_row)
+__device__ __forceinline__ uint32_t tree_prefix_diff(const uint32_t* w) {
+    uint32_t diff = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) diff |= (w[SAMPLES.tree_prefix[t]] ^ tree_cols(t)) | w[SAMPLES.tree_prefix[t] + 1];
+    return diff;
+}
+// row form: the 134 column prefixes dealt over the 16 lanes of the row (each lane's own OR; no reduction: a lane that finds
+// a wrong prefix raises the flag itself)
+__device__ __forceinline__ uint32_t prefix_diff_row(const uint32_t* w, uint32_t i) {
+    uint32_t diff = i == 0 ? tree_prefix_diff(w) : 0u;
+    // lane i: columns i, i + 16, ... (134 columns: nine rounds, the last one partly masked); straight-line, so that the
+    // table words and then the prefix words are fetched together and not one round trip after the other
+#pragma unroll
+    for (uint32_t t = 0; t < 9; t++) {
+        const uint32_t c = i + 16u * t;
+        if (c < 134u) {
+            const uint32_t po = SAMPLES.col_prefix[c];
+            const uint32_t cnt = (c >= 114u && c < 126u && ((c - 110u) & 4u)) ? 2u : 1u;  // n_samples_of: interaction columns 4-7, 12-15
+            diff |= (w[po] ^ cnt) | w[po + 1];
+        }
+    }
+    return diff;
+}
+static_assert(n_samples_of(2, 4) == 2 && n_samples_of(2, 7) == 2 && n_samples_of(2, 12) == 2 && n_samples_of(2, 3) == 1 && n_samples_of(2, 8) == 1 &&
+              n_samples_of(1, 4) == 1, "prefix_diff_row restates n_samples_of on the flat column index (tree 2 = columns 110..125)");
 
 // ------------------------------------------------------------------ row form
 // The same evaluation with ONE PROOF PER 16-LANE ROW (lane i = state word i of the Poseidon AIR's round function),
@@ -360,6 +401,8 @@ __device__ __noinline__ void oods_eval_row(const uint32_t* w, uint32_t lp, uint3
 // 4 waves per SIMD asked for (<= 128 registers, the rest spilled to scratch): the kernel is one latency-bound wave per
 // SIMD that lives for milliseconds underneath the Merkle kernels, and every 128 registers it holds cost that SIMD a
 // Merkle wave for as long.
+// (255 registers, one wave per SIMD: neither a launch bound nor amdgpu_waves_per_eu brings it down without spilling what the
+// LDS state just saved; beside the FRI trees — whose waves leave a SIMD 32 registers free — its waves start as those retire)
 __global__ __launch_bounds__(64, 4) void k_oods(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                                              uint32_t n, const ProofMeta* __restrict__ metas,
                                              ProofCtx* __restrict__ ctxs, const PubInput* __restrict__ pi,
@@ -382,8 +425,10 @@ __global__ __launch_bounds__(64, 4) void k_oods(const uint8_t* __restrict__ blob
     }
     QM31 acc, expected;
     __shared__ uint32_t qstate[QSTATE_WORDS];
-    oods_eval(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), QState{qstate + threadIdx.x}, acc, expected);
+    uint32_t pdiff = 0;
+    oods_eval(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), QState{qstate + threadIdx.x}, acc, expected, pdiff);
     if (!q_eq(acc, expected)) flags |= 1u << R_COMPOSITION;
+    if (pdiff | tree_prefix_diff(w)) flags |= 1u << R_PARSE;  // bincode shape of sampled_values (k_parse.hpp)
     if (flags) atomicOr(&c.flags, flags);
 }
 
@@ -400,6 +445,7 @@ __global__ __launch_bounds__(256) void k_oods_row(const uint8_t* __restrict__ bl
     ProofCtx& c = ctxs[p];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
     uint32_t flags = 0;
+    const uint32_t pdiff = prefix_diff_row(w, i);  // (first: its loads are in flight underneath the arithmetic below)
     QM31 z = ldq(c.z), alpha = ldq(c.alpha), plonk_sum = ldq(w + W_PLONK_SUM), poseidon_sum = ldq(w + W_POSEIDON_SUM);
     {  // fiat_shamir/src/lib.rs:133-141: the public inputs are dealt to the lanes, their fractions added over the row
         QM31 sum = q_zero();
@@ -414,6 +460,7 @@ __global__ __launch_bounds__(256) void k_oods_row(const uint8_t* __restrict__ bl
     oods_eval_row(w, m.lp, m.lq, plonk_sum, poseidon_sum, z, alpha, ldq(c.rc), ldq(c.oods_x), i, acc, expected);
     if (!q_eq(acc, expected)) flags |= 1u << R_COMPOSITION;
     if (flags && i == 0) atomicOr(&c.flags, flags);
+    if (pdiff) atomicOr(&c.flags, 1u << R_PARSE);  // bincode shape of sampled_values (k_parse.hpp)
 }
 
 __global__ __launch_bounds__(256) void k_oods_row_probe(const uint32_t* __restrict__ prefix, uint32_t prefix_words,
@@ -431,6 +478,20 @@ __global__ __launch_bounds__(256) void k_oods_row_probe(const uint32_t* __restri
     }
 }
 
+// rsv_transcript (the one-proof probe runs the parser and the transcript only): the prefixes of sampled_values, one lane per proof
+__global__ __launch_bounds__(64) void k_prefix_check(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets, uint32_t n,
+                                                     const ProofMeta* __restrict__ metas, ProofCtx* __restrict__ ctxs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || metas[p].reason != R_OK) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(blob + offsets[p]);
+    uint32_t diff = tree_prefix_diff(w);
+    for (uint32_t k = 0; k < (uint32_t)N_SAMPLES; k++) {
+        const uint32_t po = SAMPLES.pre_of[k];
+        if (po) diff |= (w[po] ^ (uint32_t)SAMPLES.cnt_of[k]) | w[po + 1];
+    }
+    if (diff) atomicOr(&ctxs[p].flags, 1u << R_PARSE);
+}
+
 // Probe (rsv_oods_eval): item i = a proof prefix of OODS_PREFIX_WORDS words (only the sampled values are read) plus
 // 26 parameter words lp, lq, plonk_sum, poseidon_sum, z, alpha, random_coeff, oods.x; out = accumulator | expected.
 constexpr uint32_t OODS_PARAM_WORDS = 26;
@@ -441,8 +502,9 @@ __global__ __launch_bounds__(64, 4) void k_oods_probe(const uint32_t* __restrict
     const uint32_t* pr = params + (size_t)i * OODS_PARAM_WORDS;
     QM31 acc, expected;
     __shared__ uint32_t qstate[QSTATE_WORDS];
+    uint32_t pdiff = 0;  // (the probe evaluates on arbitrary samples: the prefixes are the full pipeline's business)
     oods_eval(prefix + (size_t)i * prefix_words, pr[0], pr[1], ldq(pr + 2), ldq(pr + 6), ldq(pr + 10), ldq(pr + 14), ldq(pr + 18),
-              ldq(pr + 22), QState{qstate + threadIdx.x}, acc, expected);
+              ldq(pr + 22), QState{qstate + threadIdx.x}, acc, expected, pdiff);
     stq(out + (size_t)i * 8, acc);
     stq(out + (size_t)i * 8 + 4, expected);
 }

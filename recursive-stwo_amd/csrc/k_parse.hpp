@@ -79,20 +79,11 @@ __global__ __launch_bounds__(64) void k_parse(const uint8_t* __restrict__ blob, 
     if (M > MAX_LOG) return;
     if (A < last + b + 1 || B < last + b + 1) return;
     if (r.w[W_NCOMMIT] != 4 || r.w[W_NCOMMIT + 1] != 0 || r.w[W_NTREES] != 4 || r.w[W_NTREES + 1] != 0) return;
-    // constant-shape sampled_values: 4 trees of 50/60/16/8 columns with 1 or 2 mask points
-    // (straight-line: the 142 prefixes sit at compile-time offsets, so all their loads are independent and issued in
-    // batches; as a loop each prefix cost the lane a memory round trip of its own — a third of this kernel's time)
-    uint32_t diff = 0;  // OR of (word ^ expected) over every prefix
-#pragma unroll
-    for (int t = 0; t < 4; t++) diff |= (r.w[SAMPLES.tree_prefix[t]] ^ tree_cols(t)) | r.w[SAMPLES.tree_prefix[t] + 1];
-#pragma unroll
-    for (int c_all = 0; c_all < 134; c_all++) {
-        const int t = c_all < 50 ? 0 : c_all < 110 ? 1 : c_all < 126 ? 2 : 3;
-        const int c = c_all - (t == 0 ? 0 : t == 1 ? 50 : t == 2 ? 110 : 126);
-        diff |= (r.w[SAMPLES.col_prefix[c_all]] ^ n_samples_of(t, c)) | r.w[SAMPLES.col_prefix[c_all] + 1];
-    }
+    // constant-shape sampled_values: 4 trees of 50/60/16/8 columns with 1 or 2 mask points.  The 4 + 134 length prefixes of
+    // that region sit between the sampled values, which this kernel has no other reason to touch: they are checked where the
+    // values are read anyway (k_oods / k_oods_row: EvalCtx::smp; a wrong prefix raises RSV_R_PARSE there) — here the 138
+    // strided reads fetched the whole 3.4 KB region a second time (10 KB of HBM traffic per proof for a 1 KB job).
     static_assert(tree_cols(0) == 50 && tree_cols(1) == 60 && tree_cols(2) == 16 && tree_cols(3) == 8, "column counts of the four trees");
-    if (diff) return;
     r.pos = SAMPLES.end;
     if (r.len() != 4) return;
     for (int t = 0; t < 4; t++) parse_decommit(r, m.hw_off[t], m.hw_n[t]);

@@ -39,6 +39,8 @@ struct SampleTable {
     uint16_t col_prefix[134]; // word offset of each column's u64 sample-count prefix
     uint16_t tree_prefix[4];  // word offset of each tree's u64 column-count prefix
     uint16_t end;             // first word after sampled_values (= decommitments prefix)
+    uint16_t pre_of[N_SAMPLES];  // sample -> word offset of its column's u64 sample-count prefix if it is the column's FIRST sample, else 0
+    uint8_t cnt_of[N_SAMPLES];   // ... and the count that prefix must hold (1 or 2)
 };
 __host__ __device__ constexpr SampleTable make_sample_table() {
     SampleTable t{};
@@ -48,6 +50,8 @@ __host__ __device__ constexpr SampleTable make_sample_table() {
         pos += 2;
         for (uint32_t c = 0; c < tree_cols(tr); c++) {
             t.col_prefix[c_all++] = (uint16_t)pos;
+            t.pre_of[k] = (uint16_t)pos;
+            t.cnt_of[k] = (uint8_t)n_samples_of(tr, (int)c);
             pos += 2;
             for (uint32_t s = 0; s < n_samples_of(tr, (int)c); s++) {
                 t.off[k++] = (uint16_t)pos;

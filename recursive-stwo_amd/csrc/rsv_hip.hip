@@ -53,6 +53,7 @@ struct Options {
     int tree_pace = 0;         // 0 auto (by batch size), 1 the tree kernels on the paced permutation instances, 2 on the unpaced ones, 3 in the row form (16 threads per path)
     int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
     int cap_mid = 0;           // 0 auto (buckets whose in-kernel cap levels fill their waves badly), 1 every bucket hands over at the cap level (k_cap_mid + k_cap_top), 2 none
+    int oods_early = 0;        // 0 / 2 the OODS check behind the trace trees (side stream), 1 (experiment) right behind the transcript on the aux stream
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
     int witness_small_log = 0;        // 0 default, else 1 + log2(proofs per workgroup) of that form
@@ -88,7 +89,7 @@ struct rsv_ctx {
     hipStream_t side = nullptr;  // row hashes, quotient constants, k_query, FRI trees: underneath the main stream
     hipStream_t aux = nullptr;   // the front half of a small batch's transcript, next to the parser
     hipEvent_t ev_begin = nullptr, ev_front = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr, ev_ext = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scan = nullptr, ev_plan = nullptr, ev_query = nullptr, ev_tr = nullptr, ev_ids = nullptr, ev_ext = nullptr, ev_oods = nullptr;
     // reusable HBM workspace for rsv_verify_batch_dev
     void* ws = nullptr;        // per-query stages (plan, FRI leaf values)
     size_t ws_bytes = 0;
@@ -189,6 +190,7 @@ int rsv_ctx_create(int device, rsv_ctx** out) {
         hipEventCreateWithFlags(&c->ev_tr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ids, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_oods, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess) {
         rsv_ctx_destroy(c);
         return RSV_E_DEVICE;
@@ -211,6 +213,7 @@ void rsv_ctx_destroy(rsv_ctx* c) {
     if (c->ev_ids) (void)hipEventDestroy(c->ev_ids);
     if (c->ev_query) (void)hipEventDestroy(c->ev_query);
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
+    if (c->ev_oods) (void)hipEventDestroy(c->ev_oods);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -262,6 +265,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_STAGE_TIMES: return tri(&o.stage_times);
         case RSV_OPT_QUERY_FORM: return tri(&o.query_form);
         case RSV_OPT_CAP_MID: return tri(&o.cap_mid);
+        case RSV_OPT_OODS_EARLY: return tri(&o.oods_early);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;
             o.witness_walk_log = (int)value; return RSV_OK;

@@ -28,6 +28,8 @@ rsv = rsvload.load_package()
 
 
 def main():
+    import bench  # (the repo root is on the path: the kernel sources' hash names the build this corpus ran on)
+    print(f"# tests/soak.py {' '.join(sys.argv[1:])} — kernel sources {bench.kernel_sources_sha()}", flush=True)
     for a in [a for a in sys.argv[1:] if "=" in a]:  # kernel-form overrides
         name, value = a.split("=", 1)
         rsv.set_default_option(name, value if value in rsv.OPTION_VALUES else int(value))

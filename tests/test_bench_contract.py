@@ -105,3 +105,14 @@ def test_committed_profile_holds_the_large_batch_line():
     if "pipeline_valu_insts" in prof:
         frac = prof["pipeline_valu_insts"] / (prof["bench_ms_per_step"] * 1e-3) / (1024 * 2.4e9 / 2.0)
         assert 0.5 <= frac <= 1.0, frac
+    # the evidence is ONE build — the profile and the large soak carry the hash of the same kernel sources
+    # (tests/soak.py prints it; tools/round5_artifacts.sh runs the soak last), and those are the committed sources
+    tag = prof["tag"].split("_")[0]
+    soak = os.path.join(ROOT, "profiles", f"{tag}_soak_large.txt")
+    if tag >= "r5":
+        import re
+        shas = set(re.findall(r"kernel sources ([0-9a-f]{16})", open(soak).read()))
+        assert shas == {prof["kernel_sources_sha"]}, (shas, prof["kernel_sources_sha"])
+        sys.path.insert(0, ROOT)
+        import bench
+        assert bench.kernel_sources_sha() == prof["kernel_sources_sha"], "profiles/ were taken on other kernel sources than the committed ones"

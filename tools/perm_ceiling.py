@@ -23,8 +23,12 @@ Dynamic VALU instruction mix of ONE wave-level call of rsv::poseidon2() (64 perm
                                               became literals (before: 4 428 with 736 addend-mads, 15 650 cycles, 10.05 G/s)
 
 => 15 129 cycles-at-2.4-GHz per 64 permutations per SIMD => 1024 SIMDs x 2.4e9 / 15 129 x 64 = 10.40 G permutations/s.
-(The lab's "cycles at 2.4 GHz" are wall time x 2.4 GHz: whatever clock the chip really holds under an all-VALU load is
-already inside them, so the ceiling is a time, not a cycle, bound.)
+(The lab's "cycles at 2.4 GHz" are wall time x 2.4 GHz.  Round 5 separated clock from issue cost (tools/valu_clock.sh,
+profiles/r5_valu_lab_*): under the lab's dense VALU load GRBM_GUI_ACTIVE holds 2.35-2.40 GHz — v_and_b32 at 4 waves per
+SIMD: 2.242 ms at 2.383 GHz for 2 097 152 wave-instructions per SIMD = 2.55 REAL cycles each — so the fast class's 2.5
+against the nominal 2 (MI355X_MICROARCH.md) is issue overhead of the SIMD, not a power state; one wave alone issues every
+5.1 cycles.  The per-wave clock64 column of the lab shows the arbiter instead: it favours a SIMD's oldest wave, the waves
+finish one after the other, and only the longest-lived one spans the launch.)
 
 Usage: python tools/perm_ceiling.py [path/to/asm]   — with an assembly listing (hipcc -S --cuda-device-only) it also
 prints the STATIC opcode histogram of rsv::poseidon2 as a cross-check of the class membership."""
