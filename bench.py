@@ -348,7 +348,16 @@ def main():
     n = last - first
     d_blob, d_offsets, plen, tam, fix_idx = build_batch_on_device(torch, dev, n, first, fixtures, args.order, n_total)
     total_bytes = int(plen.sum())
-    sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch, plan=plan, exchange=args.exchange)
+    # (RCCL prints a version banner on STDOUT when a communicator is first created; this process prints ONE JSON line there)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        sv = sharding.ShardedVerifier(rsv, n_total, rank, world, dev_index, dist, torch, plan=plan, exchange=args.exchange)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if args.stage_times:  # the roofline's kernel time comes from HIP events on the verifier's streams
         try:
             sv.ctx.set_option("stage_times", "on")

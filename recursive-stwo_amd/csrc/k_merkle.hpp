@@ -225,7 +225,7 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
                          // ti >= T: a launch's grid covers the deepest bucket's FRI layers, this bucket has fewer trees
         const uint32_t g2 = t >> Lt, pp = t & ((1u << Lt) - 1u);
         if (g2 < per_block && slot0 + g2 < n_slots) {
-            const unsigned long long cm = grp_desc[g2].active ? mask[bufi][g2] : 0ull;
+            const unsigned long long cm = grp_desc[g2].active ? mask[bufi][g2] : 0ull;  // (Lt == Lc <= 6: up to 64 positions)
             const size_t idx = (size_t)(slot0 + g2) * T + ti;
             if (pp == 0) capm[idx] = cm;
             if ((cm >> pp) & 1u) store_hash(capn + ((idx << Lt) + pp) * 8, load_hash(&xch[bufi][(g2 << Lt) + pp][0]));
@@ -258,8 +258,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
     const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
     const int t = blockIdx.y;
-    const bool slot_ok = grp < per_block && slot_ < a.n;
-    bool live = slot_ok;
+    bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq;
@@ -304,8 +303,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
             }
         }
     }
-    const bool direct = Lc && a.Lt == Lc;  // the level-Lc nodes go straight to the cap kernels (no in-kernel cap)
-    if (!direct && Lc && j == 0 && grp < per_block) {
+    if (Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
         d.active = live ? 1u : 0u;
         if (live) {
@@ -399,22 +397,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
         const uint32_t fl = (ok ? 0u : 1u << (R_MERKLE_T0 + t)) | ((bad || want_hw != hw_n) ? F_RESCAN : 0u);
         if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
-    if (direct) {
-        // hand-over at the cap level without an in-kernel cap: every path writes its level-Lc node (paths that share it write
-        // the same words), the presence mask is collected in LDS; every (slot, tree) of the launch gets a mask, a rejected
-        // proof an empty one
-        __syncthreads();
-        if (tid < 64) capmask[0][tid] = 0;
-        __syncthreads();
-        const size_t idx = (size_t)slot_ * 4 + t;
-        if (live) {
-            const uint32_t pos = qj >> (M - Lc);
-            store_hash(a.tcapn + ((idx << Lc) + pos) * 8, cur);
-            atomicOr(&capmask[0][grp], 1ull << pos);
-        }
-        __syncthreads();
-        if (slot_ok && j == 0) a.tcapm[idx] = live ? capmask[0][grp] : 0ull;
-    } else if (Lc) {
+    if (Lc) {
         uint32_t* emit = (a.path_sib && live) ? a.path_sib + (((size_t)slot_ * 4 + t) * G + a.ctxs[p].qperm[j]) * a.pl.maxM * 8 : nullptr;
         if constexpr (FLOW) {
             // this path's record of the step from level Lc: behind the leaf sponge, the steps above and — every column
@@ -460,8 +443,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
     const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
     const uint32_t slot = f.y_of[blockIdx.y];  // which FRI tree this grid row hashes (a permutation chosen by the host for small launches)
-    const bool slot_ok = grp < per_block && slot_ < a.n;
-    bool live = slot_ok;
+    bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
     live = live && m->reason == R_OK && j < m->nq && (slot == 0 || slot - 1 < m->n_inner);
@@ -515,8 +497,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
             }
         }
     }
-    const bool direct = Lc && a.Lt == Lc;  // the level-Lc nodes go straight to the cap kernels (no in-kernel cap)
-    if (!direct && Lc && j == 0 && grp < per_block) {
+    if (Lc && j == 0 && grp < per_block) {
         CapGroup& d = capgrp[grp];
         d.active = live ? 1u : 0u;
         if (live) {
@@ -625,19 +606,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
         const uint32_t fl = (ok ? 0u : 1u << (slot == 0 ? R_FRI_FIRST : R_FRI_INNER)) | ((bad || want_hw != L->hash_n) ? F_RESCAN : 0u);
         if (fl) atomicOr(&a.ctxs[p].flags, fl);
     }
-    if (direct) {  // hand-over at the cap level without an in-kernel cap (see k_trace_merkle)
-        __syncthreads();
-        if (tid < 64) capmask[0][tid] = 0;
-        __syncthreads();
-        const size_t idx = (size_t)slot_ * (1u + a.maxInner) + slot;
-        if (live) {
-            const uint32_t pos = qj >> (M - Lc);
-            store_hash(a.pcapn + ((idx << Lc) + pos) * 8, cur);
-            atomicOr(&capmask[0][grp], 1ull << pos);
-        }
-        __syncthreads();
-        if (slot_ok && j == 0 && slot < 1u + a.maxInner) a.pcapm[idx] = live ? capmask[0][grp] : 0ull;  // (a launch's grid covers the deepest bucket's FRI layers)
-    } else if (Lc) {
+    if (Lc) {
         if constexpr (FLOW) {
             // this path's record of the step from level Lc: every column level (four extra records each) lies above the cap
             capfl[0][tid] = (live && fs.rec) ? fbase + 4u + (top - Lc) + 4u * dslot : 0xFFFFFFFFu;

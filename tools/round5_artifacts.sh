@@ -27,7 +27,7 @@ python3 - <<'PY'
 import json
 for f in ("bench_flow_65536","bench_all_hints_65536","bench_131072_config3_shard","bench_total_1048576_1gpu","bench_exchange_c_65536","bench_devices_0_65536","bench_devices_00_chain_level_53248","witness_level10_1","witness_level10_1024","witness_level10_16384"):
     try:
-        d=json.load(open("gpurun_out/r5_art/%s.json"%f)); print(f, round(d["value"]), round(d["ms_per_step"],2))
+        d=json.loads([l for l in open("gpurun_out/r5_art/%s.json"%f) if l.startswith("{")][-1]); print(f, round(d["value"]), round(d["ms_per_step"],2))
     except Exception as e: print(f,"FAILED",e)
 PY
 else
