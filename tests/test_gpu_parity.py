@@ -1312,6 +1312,43 @@ def test_many_distinct_query_counts_in_one_batch(rsv):
     ctx.close()
 
 
+@pytest.mark.parametrize("mid", ["auto", "on"])
+def test_cap_kernels_with_every_cap_level(rsv, knobs, mid):
+    """The cap kernels (k_cap_mid: a lane per subtree of 4 or 8 nodes; k_cap_top) at every cap level they can meet — 3 (query
+    counts 8 .. 15), 4 (16 .. 31), 5 (32 .. 63: a level no fixture has) and 6 (64 .. 128) — and at the workgroup shapes those
+    counts give (two 128-query proofs per workgroup, four of 63, 25 of 10): the header word n_queries of genuine proofs is
+    rewritten and each proof verified under the matching configuration, so it parses, passes the proof of work and fails in
+    the Merkle stages with its own geometry; genuine proofs of four shapes in between.  Verdict and reason == the oracle's,
+    with the hand-over forced for every bucket and chosen by fill."""
+    knobs.set("tree_pace", "paced")
+    knobs.set("cap_top", "on")
+    knobs.set("cap_mid", mid)
+    base = {n: read_proof(n) for n in ("recursive_proof_16_15.bin", "level13-1.bin", "level2-1.bin", "level1-5.bin")}
+    batch, cfgs = [], []
+    for k in (4, 6, 9, 15, 20, 31, 32, 33, 40, 63, 64, 100, 128):
+        name = ("recursive_proof_16_15.bin", "level13-1.bin", "level1-5.bin")[k % 3]
+        c0 = fixture_cfg(name)
+        for rep in range(5):  # several proofs per workgroup, tampered ones among them
+            b = bytearray(ob.tamper(base[name], 3 * k + rep) if rep == 3 else base[name])
+            b[4 * 13:4 * 13 + 4] = int(k).to_bytes(4, "little")
+            batch.append(bytes(b))
+            cfgs.append(type(c0)(c0.pow_bits, c0.log_blowup_factor, c0.log_last_layer_degree_bound, k))
+        g = list(base)[len(batch) % 4]
+        batch.append(base[g]); cfgs.append(fixture_cfg(g))
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    for lo in range(0, len(batch), 30):  # (16 configurations per call: RSV_MAX_CFGS)
+        acc, reason = rsv.verify_batch(batch[lo:lo + 30], cfgs[lo:lo + 30])
+        diff = np.nonzero((acc != oacc[lo:lo + 30]) | (reason != oreason[lo:lo + 30]))[0]
+        assert diff.size == 0, [(int(i), int(cfgs[lo + i].n_queries), int(reason[i]), int(oreason[lo + i])) for i in diff[:10]]
+    assert int(oacc.sum()) == 13  # exactly the genuine proofs
+    # one configuration per call (the device-side slot order sizes its launch for the deepest trees the parser admits)
+    for k in (33, 100):
+        one = [b for b, c in zip(batch, cfgs) if c.n_queries == k]
+        a1, r1 = rsv.verify_batch(one, cfgs[[c.n_queries for c in cfgs].index(k)])
+        o1, q1 = ob.verify_batch(one, cfgs[[c.n_queries for c in cfgs].index(k)])
+        assert a1.tolist() == o1.tolist() and r1.tolist() == q1.tolist(), k
+
+
 def test_mixed_batch_split_into_several_launch_groups(rsv, monkeypatch):
     """A mixed batch whose per-query workspaces exceed the budget: the launcher cuts it into several groups of
     (bucket, slot range) entries, some buckets split across groups.  Verdicts == those of the unconstrained run ==
