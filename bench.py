@@ -500,6 +500,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC bytes measured by tools/profile.sh on THESE kernel sources, else null.
     traffic, traffic_note = None, "traffic: no PMC profile of these kernel sources under profiles/ (tools/profile.sh writes pmc_latest.json)"
     valu_issue_frac = None
+    valu_issue_frac_solo = kernel_solo_ms = None  # the profiled launch running ALONE (counter pass): counters and time of one run
     pipeline_valu_issue_frac = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
@@ -516,6 +517,7 @@ def main():
             # kernel time, against one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz (the nominal rate)
             if pk.get("SQ_INSTS_VALU") and dom_ms > 0:
                 valu_issue_frac = float(pk["SQ_INSTS_VALU"]) / (dom_ms * 1e-3) / (SIMDS * LAB_GHZ * 1e9 / 2.0)
+            valu_issue_frac_solo, kernel_solo_ms = pk.get("valu_issue_frac_solo"), pk.get("solo_ms")
             # the whole step: every pipeline kernel's VALU instructions over the step's wall time (kernels overlap, so a
             # single kernel's span also holds the others' instructions; this figure does not depend on the attribution)
             if prof.get("pipeline_valu_insts"):
@@ -530,6 +532,7 @@ def main():
     # 8 TB/s), as SURVEY 8d defines them; valu_issue_frac is the binding one.
     roofline = {"bound": "valu", "nominal_bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue_frac": valu_issue_frac,
+                "valu_issue_frac_solo": valu_issue_frac_solo, "kernel_solo_ms": kernel_solo_ms,
                 "pipeline_valu_issue_frac": pipeline_valu_issue_frac,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dom_ms if stage_avg else None,
                 "pipeline_ms": ms_per_step, "pipeline_GBps": pipeline_gbps, "pipeline_frac": pipeline_gbps / HBM_PEAK_GBPS,
@@ -537,7 +540,9 @@ def main():
                 "note": "31-bit modular integer hashing: VALU-issue bound, not HBM bound (SURVEY §8d); see valu. "
                         "frac charges the whole proof to the dominant kernel (SURVEY §8d's numerator); pipeline_frac "
                         "is the same bytes over the wall time of a step on rank 0.  valu_issue_frac = SQ_INSTS_VALU of the "
-                        "profiled launch / kernel_ms / (1 024 SIMDs x 2.4 GHz / 2).  kernel_ms / stage_ms are HIP-event "
+                        "profiled launch / kernel_ms / (1 024 SIMDs x 2.4 GHz / 2); valu_issue_frac_solo = the same counter over kernel_solo_ms, "
+                        "the launch's duration in the counter pass, where it runs alone (kernel_ms is a span beside the other stream's "
+                        "kernels).  kernel_ms / stage_ms are HIP-event "
                         "spans on the verifier's streams; side-stream stages overlap the main stream, so stage_ms do not "
                         "add up to pipeline_ms, and a span includes the time a launch waits for room on the chip: "
                         "'cap_top(span)' is ~0.5 ms of work that sits underneath the FRI trees for most of their duration.  " + traffic_note}
