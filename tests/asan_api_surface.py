@@ -33,6 +33,29 @@ for n, w in [(10, 3), (1000, 7), (65, 2), (1, 1), (31, 4), (4097, 8), (3, 8), (0
     g = rng.integers(0, 2**32, (w, sw), dtype=np.uint64).astype(np.uint32)   # garbage above the slices' own bits
     if n:
         rsv.exchange_assemble(n, w, g)
+# round 5: the byte-balanced plan, the planned assembly (unequal slice widths, garbage above every slice's own bits), the
+# configuration check — pure host arithmetic under the sanitizers
+for trial in range(200):
+    n = int(rng.integers(0, 300))
+    w = int(rng.integers(1, 20))
+    lens = rng.integers(0, 1 << 20, n, dtype=np.uint64) if trial % 4 else np.zeros(n, np.uint64)
+    lo, hi = rsv.shard_plan(lens, w)
+    assert lo[0] == 0 and hi[-1] == n and all(lo[r + 1] == hi[r] and hi[r] >= lo[r] for r in range(w - 1))
+    if n:
+        sw = max(1, max((h - l + 31) // 32 for l, h in zip(lo, hi)))
+        g = rng.integers(0, 2**32, (w, sw), dtype=np.uint64).astype(np.uint32)
+        acc, bm = rsv.exchange_assemble(n, w, g, plan=(lo, hi))
+        assert len(acc) == n and np.array_equal(np.unpackbits(bm.view(np.uint8), bitorder="little")[:n], acc)
+lo_a, hi_a = (ctypes.c_size_t * 3)(0, 5, 4), (ctypes.c_size_t * 3)(5, 4, 9)          # not a plan: RSV_E_SIZE, nothing read beyond it
+assert lib.rsv_exchange_assemble_plan(3, lo_a, hi_a, np.zeros(8, np.uint32).ctypes.data_as(rsv._u32p), np.zeros(16, np.uint8).ctypes.data_as(rsv._u8p), None) == -2
+for c in ((20, 5, 8, 16), (31, 5, 8, 16), (20, 0, 8, 16), (20, 5, 17, 16), (20, 5, 8, 129), (2**32 - 1,) * 4):
+    rsv.cfg_check(rsv.PcsConfig(*c))
+for cfg in (rsv.PcsConfig(20, 5, 8, 129), rsv.PcsConfig(20, 17, 8, 16)):            # beyond the limits: RSV_E_SIZE before any device call
+    try:
+        rsv.verify_batch([b"\0" * 64], cfg)
+        raise SystemExit("a configuration beyond the limits was accepted")
+    except rsv.RsvError as e:
+        assert e.code == -2, e.code
 mh = ctypes.c_void_p()
 assert lib.rsv_multi_create((ctypes.c_int * 2)(0, 1), 2, ctypes.byref(mh)) == -3 and not mh.value
 assert lib.rsv_host_alloc(1 << 20, ctypes.byref(mh)) == -3
