@@ -677,9 +677,20 @@ struct Verifier {
               "rsv_verify_batch_host");
     }
     // The same job over several devices from this ONE process — the reference's driver is one process that walks the whole
-    // chain (examples/multi-proofs/src/main.rs:198-295): contiguous shards (rsv_shard_range), one host thread per device,
+    // chain (examples/multi-proofs/src/main.rs:198-295): contiguous shards balanced by bytes (rsv_shard_plan), one host thread per device,
     // verdicts + accept bitmap + count assembled on the host (rsv_multi_verify_batch_host; nothing is exchanged between
     // the devices).  `devices` may name a device more than once.  Returns the number of accepted proofs.
+    // How a job of these proofs is cut over `world` ranks: contiguous [lo, hi) per rank, balanced by bytes (rsv_shard_plan) —
+    // what verify_batch_multi does inside, and what N processes of one GPU each compute for themselves (same lengths, same plan).
+    static std::vector<std::pair<size_t, size_t>> shard_plan(const std::vector<std::vector<uint8_t>>& proofs, size_t world) {
+        std::vector<uint64_t> lens(proofs.size());
+        for (size_t i = 0; i < proofs.size(); i++) lens[i] = proofs[i].size();
+        std::vector<size_t> lo(world), hi(world);
+        check(rsv_shard_plan(lens.data(), lens.size(), world, lo.data(), hi.data()), "rsv_shard_plan");
+        std::vector<std::pair<size_t, size_t>> out(world);
+        for (size_t r = 0; r < world; r++) out[r] = {lo[r], hi[r]};
+        return out;
+    }
     static uint64_t verify_batch_multi(const std::vector<int>& devices, const std::vector<std::vector<uint8_t>>& proofs,
                                        const std::vector<PcsConfig>& configs, const Inputs& inputs, std::vector<uint8_t>& accept,
                                        std::vector<uint8_t>& reason, std::vector<uint32_t>* bitmap = nullptr) {

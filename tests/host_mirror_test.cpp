@@ -5,6 +5,7 @@
 //   test_fiat_shamir            components/recursive/fiat_shamir/src/lib.rs:197-236 (challenges: SURVEY App. C)
 //   test_folding (= full verify) components/recursive/folding/src/lib.rs:231-303
 //   test_poseidon_flow          constraint_system/src/plonk_with_poseidon.rs:282-318,468-519 on the GPU-recorded flow
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -287,6 +288,18 @@ static void test_multi(const std::vector<uint8_t>& small, const std::vector<uint
     EXPECT(lo == 0 && hi == 4);
     rsv_shard_range(10, 2, 3, &lo, &hi);
     EXPECT(lo == 7 && hi == 10);
+    // the byte-balanced plan over this job (proof 9 is empty): contiguous, covering, and the heaviest shard within one proof of the lightest
+    {
+        const auto plan = Verifier::shard_plan(proofs, 3);
+        EXPECT(plan.size() == 3 && plan[0].first == 0 && plan[2].second == proofs.size() && plan[0].second == plan[1].first && plan[1].second == plan[2].first);
+        size_t bytes[3] = {0, 0, 0}, longest = 0;
+        for (size_t r = 0; r < 3; r++)
+            for (size_t i = plan[r].first; i < plan[r].second; i++) { bytes[r] += proofs[i].size(); longest = std::max(longest, proofs[i].size()); }
+        const size_t mx = std::max(bytes[0], std::max(bytes[1], bytes[2])), mn = std::min(bytes[0], std::min(bytes[1], bytes[2]));
+        EXPECT(mx - mn <= 2 * longest);
+        rsv_pcs_config beyond{20, 5, 8, 129};
+        EXPECT(rsv_cfg_check(&beyond) == RSV_E_SIZE);
+    }
     // more contexts than proofs: the empty shards are skipped
     std::vector<std::vector<uint8_t>> two(proofs.begin(), proofs.begin() + 2);
     std::vector<PcsConfig> two_cfg(configs.begin(), configs.begin() + 2);
