@@ -625,6 +625,13 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
 // (7) slots per tree.  Same walk as merkle_cap (same witness ranks, same flags), nodes in registers.
 struct CapTopIndex {
     uint32_t first_block[MAX_FUSED + 1];  // blocks of 256 (slot, tree) items per argument set
+    // Item order inside an argument set.  0: slot-major — the trees of a proof side by side, a wave touches 16 proofs.  1:
+    // tree-major — a wave holds 64 proofs' copies of ONE tree: a launch under one configuration is sized for the deepest
+    // trees the parser admits, and the lanes of the FRI layers no proof of the batch has then leave as whole waves; but a
+    // wave's loads go to 64 proofs (64 pages) instead of 16, which a small launch — few waves, their three or seven
+    // dependent hashes on the step's critical chain — pays for: 4 096 proofs 2.55 -> 2.63 ms, 8 192: 4.70 -> 4.74
+    // (gpurun_out/r5_m/ab.txt, r5_p_ab.txt).  The host picks by the launch's size — a TEMPLATE argument of the cap kernels: with
+    // the order chosen at run time from this struct the small launch was as slow as with tree-major (measured, same box).
 };
 
 static_assert(sizeof(Fused<MerkleArgs>) + sizeof(CapTopIndex) + 8 <= 4096 && sizeof(Fused<MerkleArgs>) + sizeof(FlowArgs) <= 4096,
@@ -691,7 +698,7 @@ __device__ __forceinline__ void cap_top_walk(const MerkleArgs& a, uint32_t slot_
     }
 }
 
-template <int PACE = 1>
+template <int PACE = 1, bool TREE_MAJOR = false>
 __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
     RSV_TAG(pair ? 4 : 3);
     uint32_t k = 0;
@@ -700,9 +707,8 @@ __global__ __launch_bounds__(256) void k_cap_top(Fused<MerkleArgs> f, CapTopInde
     const uint32_t T = pair ? 1u + a.maxInner : 4u;
     const uint64_t item = (uint64_t)(blockIdx.x - ix.first_block[k]) * 256 + threadIdx.x;
     if (!a.Lt || item >= (uint64_t)a.n * T) return;
-    // tree-major: a launch under one configuration is sized for the deepest trees the parser admits, and the lanes of the
-    // FRI layers no proof of the batch has leave as whole waves
-    const uint32_t ti = (uint32_t)(item / a.n), slot_ = (uint32_t)(item % a.n);
+    const uint32_t ti = TREE_MAJOR ? (uint32_t)(item / a.n) : (uint32_t)(item % T);
+    const uint32_t slot_ = TREE_MAJOR ? (uint32_t)(item % a.n) : (uint32_t)(item / T);
     if (a.Lt2 == 2) cap_top_walk<2, PACE>(a, slot_, ti, pair != 0);
     else cap_top_walk<3, PACE>(a, slot_, ti, pair != 0);
 }
@@ -791,7 +797,7 @@ __device__ __forceinline__ void cap_mid_walk(const MerkleArgs& a, uint32_t slot_
     if (any) store_hash((pair ? a.pcapn2 : a.tcapn2) + ((idx << Lt2) + sub) * 8, node[0]);
 }
 
-template <int PACE = 1>
+template <int PACE = 1, bool TREE_MAJOR = false>
 __global__ __launch_bounds__(256) void k_cap_mid(Fused<MerkleArgs> f, CapTopIndex ix, uint32_t pair) {
     RSV_TAG(pair ? 4 : 3);
     uint32_t k = 0;
@@ -803,7 +809,8 @@ __global__ __launch_bounds__(256) void k_cap_mid(Fused<MerkleArgs> f, CapTopInde
     if (item >= ((uint64_t)a.n * T << a.Lt2)) return;
     const uint32_t sub = (uint32_t)(item & ((1u << a.Lt2) - 1u));
     const uint64_t tree = item >> a.Lt2;
-    const uint32_t ti = (uint32_t)(tree / a.n), slot_ = (uint32_t)(tree % a.n);  // tree-major, as k_cap_top
+    const uint32_t ti = TREE_MAJOR ? (uint32_t)(tree / a.n) : (uint32_t)(tree % T);  // (item order: CapTopIndex)
+    const uint32_t slot_ = TREE_MAJOR ? (uint32_t)(tree % a.n) : (uint32_t)(tree / T);
     if (a.Lt - a.Lt2 == 2) cap_mid_walk<2, PACE>(a, slot_, ti, sub, pair != 0);
     else cap_mid_walk<3, PACE>(a, slot_, ti, sub, pair != 0);
 }
