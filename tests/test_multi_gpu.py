@@ -331,6 +331,19 @@ def test_bench_c_abi_exchange_and_one_process_lines():
     assert dr["config"]["order"] == "level" and dr["config"]["proofs_rank0"] == 1300
 
 
+def test_bench_two_ranks_level_ordered_chain_cut_by_bytes():
+    """Two rank PROCESSES (rehearsal: both on cuda:0, exchange over gloo) on the reference's level-ordered chain as a job of
+    fixed size: every rank computes the same rsv_shard_plan from the job's lengths, the shards are of very unequal COUNT and
+    nearly equal bytes, the slices of the all-gather of unequal width — and every rank checks the whole job's accept map."""
+    d = _bench(["--gpus", "2", "--rehearsal", "--workload", "chain", "--order", "level", "--total-proofs", "1300", "--steps", "2", "--warmup", "1",
+                "--cpu-sample", "0", "--perm-log2", "0"], {})
+    sb = d["config"]["shard_bytes"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["order"] == "level" and "rsv_shard_plan" in d["config"]["partition"]
+    assert len(sb) == 2 and max(sb) / min(sb) < 1.02
+    assert d["config"]["proofs_rank0"] < 1300 * 0.4     # rank 0 holds the 435 KB proofs: far fewer than half of them
+    assert d["config"]["exchange"]["world_size"] == 2 and len({x["pid"] for x in d["config"]["exchange"]["devices"]}) == 2
+
+
 def _n_devices():
     try:
         import rsvload
