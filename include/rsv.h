@@ -212,6 +212,9 @@ typedef enum rsv_option {
                                      inlined, 2 inlined without wait states (recursive-stwo_amd/csrc/primitives.hpp: k_permute) */
     RSV_OPT_OODS_EARLY = 28,      /* chain layout, experiments: 0 / 2 the OODS check behind the trace trees on the side stream; 1 on a third
                                      stream right behind the transcript (measured: slower from 1 024 to 4 096 proofs, not taken) */
+    RSV_OPT_TREE_ORDER = 29,      /* workgroup order of the lane-form Merkle kernels: 0 / 2 tree by tree (grid row y = tree); 1 (measured, slower:
+                                     less HBM traffic, more time) the trees of a workgroup of proofs side by side and on one XCD, so that
+                                     their plan tables are fetched once per L2, not once per tree */
     RSV_OPT_CAP_TOP = 19          /* 0 auto (batches of >= 1 024 proofs), 1 the last two or three levels of every Merkle tree in a
                                      kernel of their own (one lane per tree), 2 inside the tree kernels (dense top-of-tree cap) */
 } rsv_option;

@@ -278,7 +278,7 @@ def device_count() -> int:
 OPTIONS = {"transcript_form": 1, "transcript_split": 2, "oods_form": 3, "qconst_form": 4, "plan_form": 5, "tree_cap": 6,
            "overlap_trees": 7, "ws_budget_mb": 8, "perm_wg_per_cu": 9, "host_chunk_mb": 10, "host_threads": 11, "debug_log": 12,
            "critical_chain": 13, "device_order": 14, "graph": 15,
-           "witness_layout": 16, "witness_small_max": 17, "witness_small_log": 18, "cap_top": 19, "witness_walk_log": 20, "flow_cap": 21, "pair_order": 22, "tree_pace": 23, "stage_times": 24, "query_form": 25, "cap_mid": 26, "perm_form": 27, "oods_early": 28}
+           "witness_layout": 16, "witness_small_max": 17, "witness_small_log": 18, "cap_top": 19, "witness_walk_log": 20, "flow_cap": 21, "pair_order": 22, "tree_pace": 23, "stage_times": 24, "query_form": 25, "cap_mid": 26, "perm_form": 27, "oods_early": 28, "tree_order": 29}
 OPTION_VALUES = {"auto": 0, "row": 1, "lane": 2, "paced": 1, "unpaced": 2, "row16": 3, "whole": 1, "split": 2, "parallel": 1, "serial": 2, "on": 1, "off": 2, "device": 1, "host": 2,
                  "by_proof": 1, "by_variable": 2}
 

@@ -245,7 +245,8 @@ __device__ __forceinline__ void merkle_cap(uint32_t (*xch)[BLOCK][8], unsigned l
 template <int BLOCK, bool FLOW = false, int PACE = 1>
 __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE_WAVES)) void k_trace_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(3);
-    RSV_FUSED_SELECT(f, a, bx);
+    RSV_TREE_BLOCK(f, bxlin, tree_y);
+    RSV_FUSED_SELECT_AT(f, a, bx, bxlin);
     constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
     const uint32_t tid = vlane<PACE>();
     row_rc_init<PACE>();
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
     const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
     const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
-    const int t = blockIdx.y;
+    const int t = (int)tree_y;
     bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_TRACE
 template <int BLOCK, bool FLOW = false, int PACE = 1>
 __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_WAVES)) void k_pair_merkle(Fused<MerkleArgs> f, FlowArgs fa) {
     RSV_TAG(4);
-    RSV_FUSED_SELECT(f, a, bx);
+    RSV_TREE_BLOCK(f, bxlin, tree_y);
+    RSV_FUSED_SELECT_AT(f, a, bx, bxlin);
     constexpr int VB = PACE == FORM_ROW ? BLOCK / 16 : BLOCK;  // lanes of this kernel's indexing per workgroup
     const uint32_t tid = vlane<PACE>();
     row_rc_init<PACE>();
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(BLOCK, PACE == FORM_ROW ? 2 : (FLOW ? 4 : RSV_PAIR_
     const uint32_t G = a.pl.G, per_block = VB / G, Lc = a.Lc;
     const uint32_t grp = tid / G, j = tid % G;
     const uint32_t slot_ = bx * per_block + grp;
-    const uint32_t slot = f.y_of[blockIdx.y];  // which FRI tree this grid row hashes (a permutation chosen by the host for small launches)
+    const uint32_t slot = f.y_of[tree_y];  // which FRI tree this workgroup hashes (a permutation chosen by the host for small launches)
     bool live = grp < per_block && slot_ < a.n;
     const uint32_t p = live ? a.pl.proof_of(slot_) : 0u;
     const ProofMeta* m = live ? &a.metas[p] : nullptr;

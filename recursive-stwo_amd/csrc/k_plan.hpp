@@ -33,11 +33,32 @@ struct Fused {
     uint32_t lds_proofs;                  // k_plan_par: proofs per workgroup its dynamic LDS tables are sized for
     uint32_t first_block[MAX_FUSED + 1];  // first blockIdx.x of set i; [nb] = grid size
     uint8_t y_of[32];                     // k_pair_merkle: FRI tree of blockIdx.y (host_logic.hpp: pair_layer_order); identity elsewhere
+    uint32_t interleave;                  // tree kernels: 1 = the XCD-aware order of RSV_TREE_BLOCK (grid x a multiple of 8), 0 = grid row y = tree
     Args a[MAX_FUSED];
 };
 // dynamic LDS of k_plan_par for workgroups of up to `proofs` proofs
 constexpr size_t plan_lds_bytes(uint32_t proofs) { return (size_t)proofs * (32 * 2 * 8 + 3 * 32 * 4); }
 // workgroup-uniform: the argument set of this block and its block index inside that set
+// Which (workgroup-of-slots, tree) a workgroup of the tree kernels takes.  Grid (x = workgroups of slots, y = trees) is
+// dispatched x-fastest, so with row y = tree all workgroups of tree 0 run first, then tree 1, ...: every tree's pass re-reads the
+// proofs' plan tables (1.5 KB per proof and tree: ~1 GB per 65 536-proof step) long after the previous pass left the L2.
+// interleave: linear id = (slot-workgroup / 8) * 8 T + tree * 8 + (slot-workgroup % 8) — the T trees of a slot-workgroup are
+// dispatched within 8 T consecutive ids and, as workgroup i goes to XCD i mod 8, to the SAME XCD (the L2 is per XCD): the
+// tables are fetched once.  (Needs grid x rounded up to a multiple of 8; the surplus workgroups leave at once.)
+#define RSV_TREE_BLOCK(FUSED_, BXLIN_, TREE_)                                                            \
+    uint32_t BXLIN_ = blockIdx.x, TREE_ = blockIdx.y;                                                    \
+    if ((FUSED_).interleave) {                                                                           \
+        const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, r_ = lin_ % (8u * gridDim.y);        \
+        TREE_ = r_ >> 3;                                                                                 \
+        BXLIN_ = (lin_ / (8u * gridDim.y)) * 8u + (r_ & 7u);                                             \
+    }                                                                                                    \
+    if (BXLIN_ >= (FUSED_).first_block[(FUSED_).nb]) return
+// as RSV_FUSED_SELECT, for a workgroup id that is not blockIdx.x
+#define RSV_FUSED_SELECT_AT(FUSED_, ARGS_, BX_, ID_)                                                    \
+    uint32_t fused_i_ = 0;                                                                               \
+    while (fused_i_ + 1 < (FUSED_).nb && (ID_) >= (FUSED_).first_block[fused_i_ + 1]) fused_i_++;         \
+    const auto& ARGS_ = (FUSED_).a[fused_i_];                                                            \
+    const uint32_t BX_ = (ID_) - (FUSED_).first_block[fused_i_]
 #define RSV_FUSED_SELECT(FUSED_, ARGS_, BX_)                                                            \
     uint32_t fused_i_ = 0;                                                                               \
     while (fused_i_ + 1 < (FUSED_).nb && blockIdx.x >= (FUSED_).first_block[fused_i_ + 1]) fused_i_++;    \

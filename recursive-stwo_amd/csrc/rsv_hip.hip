@@ -54,6 +54,7 @@ struct Options {
     int pair_order = 0;        // 0 / 1 the FRI trees of a small launch dealt out over the compute units, 2 grid row y = tree y
     int cap_mid = 0;           // 0 auto (buckets whose in-kernel cap levels fill their waves badly), 1 every bucket hands over at the cap level (k_cap_mid + k_cap_top), 2 none
     int oods_early = 0;        // 0 / 2 the OODS check behind the trace trees (side stream), 1 (experiment) right behind the transcript on the aux stream
+    int tree_order = 0;        // 0 / 2 the tree kernels' grid row y = tree, 1 (measured, slower) their workgroups in the XCD-aware interleaved order
     int cap_top = 0;           // 0 auto (batches of >= 1 024 proofs), 1 the last levels of every tree in k_cap_top, 2 inside the Merkle kernels
     long long witness_small_max = 0;  // 0 default, else 1 + the largest batch that runs the program in one launch
     int witness_small_log = 0;        // 0 default, else 1 + log2(proofs per workgroup) of that form
@@ -265,6 +266,7 @@ int rsv_ctx_set_option(rsv_ctx* c, int option, long long value) {
         case RSV_OPT_STAGE_TIMES: return tri(&o.stage_times);
         case RSV_OPT_QUERY_FORM: return tri(&o.query_form);
         case RSV_OPT_CAP_MID: return tri(&o.cap_mid);
+        case RSV_OPT_TREE_ORDER: return tri(&o.tree_order);
         case RSV_OPT_OODS_EARLY: return tri(&o.oods_early);
         case RSV_OPT_WITNESS_WALK_LOG:
             if (value < 0 || value > 7) return RSV_E_RANGE;

@@ -72,7 +72,7 @@ def test_options_are_explicit_and_validated(rsv):
     assert lib.rsv_ctx_set_option(None, 999, 1) == -2          # RSV_E_SIZE: unknown option
     assert lib.rsv_ctx_set_option(None, 0, 1) == -2
     for name in ("transcript_form", "transcript_split", "oods_form", "qconst_form", "plan_form", "tree_cap", "overlap_trees",
-                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "stage_times", "query_form", "cap_mid", "oods_early"):
+                 "critical_chain", "device_order", "graph", "witness_layout", "cap_top", "flow_cap", "pair_order", "stage_times", "query_form", "cap_mid", "oods_early", "tree_order"):
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], 3) == -5, name   # RSV_E_RANGE
         assert lib.rsv_ctx_set_option(None, rsv.OPTIONS[name], -1) == -5, name
         for v in (2, 1, 0):

@@ -1312,6 +1312,35 @@ def test_many_distinct_query_counts_in_one_batch(rsv):
     ctx.close()
 
 
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("top", ["on", "off"])
+def test_tree_workgroup_orders_match_oracle(rsv, knobs, order, top):
+    """The two workgroup orders of the lane-form tree kernels (RSV_OPT_TREE_ORDER: tree by tree — what production runs — or the
+    trees of a workgroup of proofs side by side on one XCD: less HBM traffic, more time), forced on a mixed batch of every chain shape
+    (several buckets in one launch, grid x padded to a multiple of 8, a ragged last workgroup) and on one configuration per
+    call; tampered copies among them.  Verdicts and reasons == the oracle's."""
+    names = ["level1-5.bin", "level2-1.bin", "level3-1.bin", "level4-5.bin", "level5-1.bin", "level6-1.bin", "level7-1.bin",
+             "level8-1.bin", "level9-1.bin", "level10-1.bin", "level11-1.bin", "level12-1.bin", "level13-1.bin"]
+    knobs.set("tree_pace", "paced")
+    knobs.set("tree_order", order)
+    knobs.set("cap_top", top)
+    batch, cfgs = [], []
+    for k in range(13 * 9 + 4):
+        nm = names[k % 13]
+        pr = read_proof(nm)
+        batch.append(ob.tamper(pr, 2 * k + 1) if k % 5 == 3 else pr)
+        cfgs.append(fixture_cfg(nm))
+    acc, reason = rsv.verify_batch(batch, cfgs)
+    oacc, oreason = ob.verify_batch(batch, cfgs)
+    assert acc.tolist() == oacc.tolist() and reason.tolist() == oreason.tolist() and 60 < int(acc.sum()) < 110
+    for nm, n in (("recursive_proof_16_15.bin", 150), ("level1-5.bin", 10), ("level12-1.bin", 33)):
+        pr = read_proof(nm)
+        one = [ob.tamper(pr, 7 * k) if k % 4 == 1 else pr for k in range(n)]
+        a1, r1 = rsv.verify_batch(one, fixture_cfg(nm))
+        o1, q1 = ob.verify_batch(one, fixture_cfg(nm))
+        assert a1.tolist() == o1.tolist() and r1.tolist() == q1.tolist(), nm
+
+
 @pytest.mark.parametrize("mid", ["auto", "on"])
 def test_cap_kernels_with_every_cap_level(rsv, knobs, mid):
     """The cap kernels (k_cap_mid: a lane per subtree of 4 or 8 nodes; k_cap_top) at every cap level they can meet — 3 (query
